@@ -1,0 +1,255 @@
+/*
+ * fcgpu.h -- C-ABI boundary of the MI355X-native Forward-MIS / Forward-BSDF path tracer.
+ *
+ * This is the drop-in boundary for ONE hot path of full-confession/ray-tracing: the per-sample
+ * bounce loop of `fc::forward_mis_integrator::run_once`
+ * (reference: src/integrators/forward_mis_integrator.hpp:13-210) and its degenerate subset
+ * `fc::forward_bsdf_integrator::run_once` (src/integrators/forward_bsdf_integrator.hpp:15-99),
+ * together with the renderer loop that calls it W*H*spp times
+ * (src/renderer/renderer.hpp:154-179) and the film read-out (src/renderer/renderer.hpp:115-141).
+ *
+ * A per-sample virtual call cannot feed a GPU, so the boundary sits one level up: the host
+ * describes the scene with plain-old-data arrays (the same parameters the reference's
+ * `example_scenes.hpp` passes to its constructors), the library flattens it for the device,
+ * renders whole sample passes, and hands back the film as `double rgb_sum[W*H*3]` + a sample
+ * count, exactly what `renderer::export_image` divides.
+ *
+ * Conventions: every entry point returns 0 on success or a negative FCGPU_E_* code; no C++
+ * exception crosses the ABI; `fcgpu_last_error` returns a human-readable message for the last
+ * failure on that context (or for a failed `fcgpu_create` when passed NULL).
+ * A context is single-owner: one host thread drives one context (= one GPU, one HIP stream).
+ */
+#ifndef FCGPU_H
+#define FCGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ error codes */
+#define FCGPU_OK 0
+#define FCGPU_E_INVALID (-1)   /* bad argument / inconsistent scene description */
+#define FCGPU_E_HIP (-2)       /* a HIP runtime call failed (message has the HIP error string) */
+#define FCGPU_E_NOSCENE (-3)   /* render/trace before fcgpu_upload_scene */
+#define FCGPU_E_LIMIT (-4)     /* a documented capacity was exceeded (media count, BVH depth ...) */
+#define FCGPU_E_NOMEM (-5)     /* device or host allocation failed */
+#define FCGPU_E_UNSUPPORTED (-6)
+
+/* ------------------------------------------------------------------ scene description
+ * All angles in radians, all colours linear RGB, all transforms as in
+ * src/core/transform.hpp:14-17 (T * Ry * Rx * Rz [* S]).                                  */
+
+/* surfaces: src/surfaces/{sphere,plane,mesh}_surface.hpp */
+#define FCGPU_SURFACE_SPHERE 0
+#define FCGPU_SURFACE_PLANE 1
+#define FCGPU_SURFACE_MESH 2
+
+typedef struct fcgpu_surface {
+    int32_t kind;
+    int32_t has_normals;      /* mesh: per-vertex normals present in the shared `normals` pool */
+    int32_t has_uvs;          /* mesh: per-vertex uvs present in the shared `uvs` pool          */
+    int32_t reserved;
+    double position[3];
+    double rotation[3];       /* euler x,y,z */
+    double scale[3];          /* mesh only (prs_transform); must be 1,1,1 for sphere / plane    */
+    double radius;            /* sphere: sphere_surface.hpp:11                                   */
+    double size[2];           /* plane: full extent along local x and z, plane_surface.hpp:10    */
+    uint32_t vertex_offset;   /* mesh: first vertex in the shared pools                          */
+    uint32_t vertex_count;
+    uint32_t index_offset;    /* mesh: first index in the shared `indices` pool                  */
+    uint32_t index_count;     /* multiple of 3; indices are relative to vertex_offset            */
+} fcgpu_surface;
+
+/* materials: src/materials/*.hpp. Round 1 carries constant textures only (const_texture_2d_*). */
+#define FCGPU_MATERIAL_DIFFUSE 0       /* diffuse_material.hpp:18-38       color_a = reflectance               */
+#define FCGPU_MATERIAL_MIRROR 1        /* mirror_material.hpp:20-56        color_a = reflectance, roughness     */
+#define FCGPU_MATERIAL_GLASS 2         /* glass_material.hpp:19-41         color_a = reflectance, color_b = transmittance, roughness */
+#define FCGPU_MATERIAL_PLASTIC 3       /* plastic_material.hpp:24-52       color_a = diffuse, color_b = specular, roughness, ior     */
+#define FCGPU_MATERIAL_STANDARD 4      /* standard_material.hpp:29-107     color_a = base colour, roughness[0], metalness, ior       */
+#define FCGPU_MATERIAL_TRANSMISSION 5  /* transmission_material.hpp:19-40  color_b = transmittance, roughness   */
+
+typedef struct fcgpu_material {
+    int32_t kind;
+    int32_t reserved;
+    double color_a[3];
+    double color_b[3];
+    double roughness[2];
+    double ior;
+    double metalness;
+} fcgpu_material;
+
+/* media: src/core/medium.hpp:40-54 (uniform_medium). The implicit vacuum (priority -1, ior 1)
+ * of src/core/integrator.hpp:115 is not listed.                                              */
+typedef struct fcgpu_medium {
+    int32_t priority;
+    int32_t reserved;
+    double ior;
+    double color[3];
+    double density;
+} fcgpu_medium;
+
+/* entity: src/core/acceleration_structure.hpp:12-18. Entity order defines primitive ids:
+ * primitive id = (sum of primitive counts of earlier entities) + primitive index in its surface,
+ * i.e. the index in the list entity_scene hands to the acceleration structure (scene.hpp:49-55). */
+typedef struct fcgpu_entity {
+    int32_t surface;          /* index into surfaces  */
+    int32_t material;         /* index into materials */
+    int32_t medium;           /* index into media, -1 = none */
+    int32_t emissive;         /* 1 = const_diffuse_area_light bound to this surface */
+    double emission_color[3]; /* const_diffuse_area_light.hpp:11: colour, strength  */
+    double emission_strength;
+} fcgpu_entity;
+
+/* camera: src/renderer/cameras/perspective_camera.hpp:19-27 + resolution of the render target */
+typedef struct fcgpu_camera {
+    double position[3];
+    double rotation[3];
+    double fov;               /* vertical field of view */
+    double lens_radius;       /* 0 = pinhole */
+    double focus_distance;
+    int32_t width;
+    int32_t height;
+} fcgpu_camera;
+
+#define FCGPU_ENV_NONE 0
+#define FCGPU_ENV_CONST 1     /* const_infinity_area_light.hpp (next row, not in round 1) */
+
+typedef struct fcgpu_scene_desc {
+    const fcgpu_surface* surfaces;
+    const fcgpu_material* materials;
+    const fcgpu_medium* media;
+    const fcgpu_entity* entities;
+    const float* positions;   /* 3 floats per vertex, object space (src/core/mesh.hpp:16) */
+    const float* normals;     /* 3 floats per vertex or NULL */
+    const float* uvs;         /* 2 floats per vertex or NULL */
+    const uint32_t* indices;
+    uint32_t surface_count;
+    uint32_t material_count;
+    uint32_t medium_count;
+    uint32_t entity_count;
+    uint32_t vertex_total;
+    uint32_t index_total;
+    int32_t env_kind;
+    int32_t reserved;
+    double env_color[3];
+    fcgpu_camera camera;
+} fcgpu_scene_desc;
+
+/* ------------------------------------------------------------------ options / records */
+#define FCGPU_PRECISION_F32 0   /* fast path: fp32 arithmetic, fp64 film                          */
+#define FCGPU_PRECISION_F64 1   /* reference precision: fp64 everywhere, as the reference computes */
+
+#define FCGPU_INTEGRATOR_BSDF 0 /* forward_bsdf_integrator */
+#define FCGPU_INTEGRATOR_MIS 1  /* forward_mis_integrator  */
+
+typedef struct fcgpu_options {
+    int32_t precision;          /* FCGPU_PRECISION_* */
+    int32_t sort_materials;     /* 1 = material-sorted shade queues (default), 0 = single queue */
+    double epsilon;             /* ray-origin offset (scene.hpp:182 uses 1e-6); <=0 selects the default:
+                                   1e-6 in f64, 1e-4 in f32 (1e-6 is below fp32 resolution at |p|~16) */
+    uint32_t max_paths_in_flight; /* 0 = default (2^21); a pass is split into batches of at most this */
+    uint32_t reserved;
+} fcgpu_options;
+
+typedef struct fcgpu_tile {
+    int32_t x0, y0, w, h;       /* pixel rectangle, y = 0 is the top row (perspective_camera.hpp:53) */
+} fcgpu_tile;
+
+typedef struct fcgpu_ray {      /* src/core/math.hpp ray3 + t_max */
+    double origin[3];
+    double direction[3];
+    double t_max;
+} fcgpu_ray;
+
+typedef struct fcgpu_hit {
+    double t;                   /* parametric distance, +inf on miss */
+    double b0, b1;              /* triangle barycentrics of vertex 0 and 1 (0 for sphere / plane) */
+    uint32_t prim;              /* primitive id (see fcgpu_entity), 0xFFFFFFFF on miss */
+    uint32_t reserved;
+} fcgpu_hit;
+
+typedef struct fcgpu_counters {
+    uint64_t samples;           /* run_once equivalents rendered since the last clear             */
+    uint64_t closest_rays;      /* closest-hit casts (incl. medium-boundary re-casts)             */
+    uint64_t shadow_rays;       /* any-hit casts                                                  */
+    uint64_t shadow_occluded;
+    uint64_t nan_samples;       /* samples zeroed by the NaN/Inf guard (perspective_camera.hpp:126-131) */
+    uint64_t stack_overflows;   /* traversal stack overflows (must stay 0)                        */
+    uint64_t bvh_nodes;         /* wide nodes uploaded                                            */
+    uint64_t primitives;
+    uint64_t kernel_launches;
+    uint64_t reserved[7];
+} fcgpu_counters;
+
+typedef struct fcgpu_ctx fcgpu_ctx;
+
+/* ------------------------------------------------------------------ entry points */
+
+/* Lifetime. Replaces construction/destruction of fc::renderer (renderer.hpp:23-45). */
+int fcgpu_create(int device, fcgpu_ctx** out);
+int fcgpu_destroy(fcgpu_ctx* ctx);
+const char* fcgpu_last_error(const fcgpu_ctx* ctx);
+
+int fcgpu_set_options(fcgpu_ctx* ctx, const fcgpu_options* opt);
+
+/* Replaces fc::entity_scene's constructor (scene.hpp:35-74) and the BVH build + flattening of
+ * bvh_acceleration_structure (bvh_acceleration_structure.hpp:10-24,228-365). Also (re)creates
+ * and clears the film at camera.width x camera.height (render_target.hpp:11-13).            */
+int fcgpu_upload_scene(fcgpu_ctx* ctx, const fcgpu_scene_desc* scene);
+
+/* Replaces sampler_source::set_sample seeding (sampler.hpp:33, random_sampler.hpp:26-31):
+ * the counter-based stream is keyed by (seed, pixel x, pixel y, sample index, dimension).   */
+int fcgpu_set_sampler(fcgpu_ctx* ctx, uint64_t seed);
+
+/* Replaces the pixel x sample loop of renderer::worker_thread (renderer.hpp:154-179) calling
+ * integrator::run_once (integrator.hpp:18) for every pixel of `tile` and every sample index in
+ * [sample_begin, sample_begin + sample_count). Asynchronous; ordered on the context's stream. */
+int fcgpu_render_pass(fcgpu_ctx* ctx, const fcgpu_tile* tile, uint32_t sample_begin,
+                      uint32_t sample_count, int integrator, int max_path_length,
+                      int visible_infinity_area_light);
+
+/* Parity hooks. Replace acceleration_structure::raycast_surface_point / raycast
+ * (acceleration_structure.hpp:38-39; bvh_acceleration_structure.hpp:31-91, 93-138).
+ * Host pointers; synchronous.                                                                */
+int fcgpu_trace_closest(fcgpu_ctx* ctx, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits);
+int fcgpu_trace_any(fcgpu_ctx* ctx, uint64_t n, const fcgpu_ray* rays, uint8_t* occluded);
+
+/* Same kernels on rays already resident in device memory (bench: no PCIe in the timed region).
+ * `rays_dev` / `hits_dev` / `occluded_dev` are device pointers; asynchronous.                */
+int fcgpu_trace_closest_device(fcgpu_ctx* ctx, uint64_t n, const fcgpu_ray* rays_dev,
+                               fcgpu_hit* hits_dev);
+int fcgpu_trace_any_device(fcgpu_ctx* ctx, uint64_t n, const fcgpu_ray* rays_dev,
+                           uint8_t* occluded_dev);
+
+/* Film. Replaces render_target (render_target.hpp:15-23, 30-38) and the sum/count that
+ * renderer::export_image divides (renderer.hpp:118-135): rgb_sum[(y*W + x)*3 + c] / sample_count
+ * is the pixel value the reference writes. Synchronous.                                      */
+int fcgpu_clear_film(fcgpu_ctx* ctx);
+int fcgpu_read_film(fcgpu_ctx* ctx, double* rgb_sum, uint64_t* sample_count);
+/* Device view of the film (W*H*3 doubles, unscaled radiance sums: multiply by W*H to get the
+ * reference's rgb_sum) and of the per-context sample counter, for in-place multi-GPU reduction
+ * (the analogue of the per-worker film sum, renderer.hpp:129-133).                           */
+int fcgpu_film_device_ptr(fcgpu_ctx* ctx, void** rgb_dev, uint64_t* bytes);
+int fcgpu_add_sample_count(fcgpu_ctx* ctx, int64_t delta);
+
+int fcgpu_get_counters(fcgpu_ctx* ctx, fcgpu_counters* out);
+int fcgpu_reset_counters(fcgpu_ctx* ctx);
+int fcgpu_sync(fcgpu_ctx* ctx);
+/* HIP stream the context launches on (hipStream_t as void*), so callers can bracket launches
+ * with their own events.                                                                     */
+int fcgpu_stream(fcgpu_ctx* ctx, void** stream);
+
+/* Writes the image exactly as renderer::export_image does (renderer.hpp:115-141): row-major,
+ * top row first, float32 RGB, no header, file `<name>.raw`. Synchronous.                     */
+int fcgpu_export_image(fcgpu_ctx* ctx, const char* name);
+
+/* Library/ABI version: major*1000 + minor. */
+int fcgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCGPU_H */

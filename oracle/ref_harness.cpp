@@ -1,0 +1,644 @@
+// ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product library).
+//
+// Thin C wrapper that drives the REAL reference (the unmodified headers under
+// /root/reference/src, compiled where they lie by oracle/Makefile into oracle/_ref/libfcref.so)
+// from the POD scene description of include/fcgpu.h:
+//   * builds fc::entity_scene exactly as src/example_scenes.hpp does (same constructors),
+//   * plugs the counter-based sample stream of include/fcgpu_sampler.h in as an
+//     fc::sampler_source (src/core/sampler.hpp:27-34),
+//   * runs fc::forward_mis_integrator / fc::forward_bsdf_integrator::run_once per pixel sample
+//     with the loop of renderer::worker_thread (src/renderer/renderer.hpp:154-179),
+//   * exposes the BVH and the brute-force acceleration structures for ray/hit parity,
+//   * exposes bsdf::evaluate / pdf_wi / sample_wi for per-lobe tables.
+//
+// Accommodations needed to compile the reference with g++:
+//   -fpermissive  : members named like their type (acceleration_structure.hpp:14-28 ...)
+//   `explicit` is defined away ONLY while src/core/frame.hpp is included, because
+//   src/bsdfs/normal_mapping.hpp:758 copy-list-initialises a frame through its explicit
+//   constructor (accepted by MSVC only). No reference source is copied or edited.
+//
+// g++ evaluates function arguments right-to-left; the dimension map in fcgpu_sampler.h records
+// the resulting draw -> parameter assignment.
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <optional>
+#include <thread>
+#include <vector>
+
+#include "core/math.hpp"
+#define explicit
+#include "core/frame.hpp"
+#undef explicit
+
+#include "acceleration_structures/brute_force_acceleration_structure.hpp"
+#include "acceleration_structures/bvh_acceleration_structure.hpp"
+#include "allocators/paged_allocator.hpp"
+#include "core/scene.hpp"
+#include "integrators/forward_bsdf_integrator.hpp"
+#include "integrators/forward_mis_integrator.hpp"
+#include "light_distributions/uniform_light_distribution.hpp"
+#include "lights/const_diffuse_area_light.hpp"
+#include "lights/const_infinity_area_light.hpp"
+#include "materials/diffuse_material.hpp"
+#include "materials/glass_material.hpp"
+#include "materials/mirror_material.hpp"
+#include "materials/plastic_material.hpp"
+#include "materials/standard_material.hpp"
+#include "materials/transmission_material.hpp"
+#include "renderer/cameras/perspective_camera.hpp"
+#include "surfaces/mesh_surface.hpp"
+#include "surfaces/plane_surface.hpp"
+#include "surfaces/sphere_surface.hpp"
+#include "textures/const_texture.hpp"
+
+#include "fcgpu.h"
+#include "fcgpu_sampler.h"
+
+namespace
+{
+    using namespace fc;
+
+    // ---------------------------------------------------------------- sampler
+    class counter_sampler : public sampler_source
+    {
+    public:
+        counter_sampler(int sample_count, std::uint64_t seed) : sample_count_{sample_count}, seed_{seed} {}
+
+        std::unique_ptr<sampler_source> clone() const override
+        {
+            return std::unique_ptr<sampler_source>(new counter_sampler{sample_count_, seed_});
+        }
+        int get_sample_count() const override { return sample_count_; }
+        void set_sample(vector2i const& pixel, int sample) override
+        {
+            key_ = fcgpu_sample_key(seed_, static_cast<std::uint32_t>(pixel.x), static_cast<std::uint32_t>(pixel.y),
+                                    static_cast<std::uint32_t>(sample));
+            dim_ = 0;
+        }
+        vector2 get() override
+        {
+            std::uint64_t bits{fcgpu_sample_bits(key_, dim_++)};
+            return {fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE, fcgpu_sample_y24(bits) * FCGPU_SAMPLER_SCALE};
+        }
+        void advance_dimension(int count = 1) override { dim_ += static_cast<std::uint32_t>(count); }
+        void set_dimension(int dimension_index) override { dim_ = static_cast<std::uint32_t>(dimension_index); }
+
+    private:
+        int sample_count_{};
+        std::uint64_t seed_{};
+        std::uint64_t key_{};
+        std::uint32_t dim_{};
+    };
+
+    // ---------------------------------------------------------------- recording accel
+    struct ray_record
+    {
+        double o[3];
+        double d[3];
+        double t_max;
+        double t;            // closest: hit distance (inf on miss); any: 1 / 0
+        std::uint32_t prim;  // closest: primitive id or ~0u
+        std::uint32_t kind;  // 0 closest, 1 any
+    };
+
+    struct shared_state
+    {
+        entity const* entity_base{};
+        std::vector<std::uint32_t> prim_offset{};  // per entity
+        std::atomic<std::uint64_t> closest_rays{};
+        std::atomic<std::uint64_t> any_rays{};
+        std::atomic<std::uint64_t> any_occluded{};
+        bool count{};
+        std::vector<ray_record>* log{};  // single-threaded recording only
+
+        std::uint32_t prim_id(entity_primitive const& ep) const
+        {
+            return prim_offset[static_cast<std::size_t>(ep.entity - entity_base)] + ep.primitive;
+        }
+    };
+
+    class wrapping_accel : public acceleration_structure
+    {
+    public:
+        wrapping_accel(std::vector<entity_primitive> eps, shared_state* shared)
+            : shared_{shared}
+        {
+            shared_->entity_base = eps.empty() ? nullptr : eps.front().entity;
+            // entity_scene pushes entities in order, so the first primitive belongs to entity 0
+            bvh_.reset(new bvh_acceleration_structure{eps});
+            brute_.reset(new brute_force_acceleration_structure{std::move(eps)});
+        }
+
+        bounds3 get_bounds() const override { return bvh_->get_bounds(); }
+
+        std::optional<acceleration_structure_raycast_surface_point_result> raycast_surface_point(ray3 const& ray, double t_max, allocator_wrapper& allocator) const override
+        {
+            auto result{bvh_->raycast_surface_point(ray, t_max, allocator)};
+            if(shared_->count) shared_->closest_rays.fetch_add(1, std::memory_order_relaxed);
+            if(shared_->log != nullptr)
+            {
+                ray_record r{};
+                fill(r, ray, t_max);
+                r.kind = 0;
+                if(result)
+                {
+                    r.prim = shared_->prim_id(result->entity_primitive);
+                    r.t = dot(result->p->get_position() - ray.origin, ray.direction) / dot(ray.direction, ray.direction);
+                }
+                else
+                {
+                    r.prim = ~0u;
+                    r.t = std::numeric_limits<double>::infinity();
+                }
+                shared_->log->push_back(r);
+            }
+            return result;
+        }
+
+        bool raycast(ray3 const& ray, double t_max) const override
+        {
+            bool result{bvh_->raycast(ray, t_max)};
+            if(shared_->count)
+            {
+                shared_->any_rays.fetch_add(1, std::memory_order_relaxed);
+                if(result) shared_->any_occluded.fetch_add(1, std::memory_order_relaxed);
+            }
+            if(shared_->log != nullptr)
+            {
+                ray_record r{};
+                fill(r, ray, t_max);
+                r.kind = 1;
+                r.prim = ~0u;
+                r.t = result ? 1.0 : 0.0;
+                shared_->log->push_back(r);
+            }
+            return result;
+        }
+
+        acceleration_structure const& bvh() const { return *bvh_; }
+        acceleration_structure const& brute() const { return *brute_; }
+
+    private:
+        static void fill(ray_record& r, ray3 const& ray, double t_max)
+        {
+            r.o[0] = ray.origin.x; r.o[1] = ray.origin.y; r.o[2] = ray.origin.z;
+            r.d[0] = ray.direction.x; r.d[1] = ray.direction.y; r.d[2] = ray.direction.z;
+            r.t_max = t_max;
+        }
+
+        shared_state* shared_{};
+        std::unique_ptr<acceleration_structure> bvh_{};
+        std::unique_ptr<acceleration_structure> brute_{};
+    };
+
+    class wrapping_accel_factory : public acceleration_structure_factory
+    {
+    public:
+        explicit wrapping_accel_factory(shared_state* shared, wrapping_accel const** out) : shared_{shared}, out_{out} {}
+        std::unique_ptr<acceleration_structure> create(std::vector<entity_primitive> eps) const override
+        {
+            auto* a{new wrapping_accel{std::move(eps), shared_}};
+            *out_ = a;
+            return std::unique_ptr<acceleration_structure>{a};
+        }
+
+    private:
+        shared_state* shared_{};
+        wrapping_accel const** out_{};
+    };
+
+    // ---------------------------------------------------------------- counting measurement
+    // Delegates to the reference camera; counts the samples its NaN/Inf guard zeroes
+    // (perspective_camera.hpp:126-131) instead of relying on the printed message.
+    class counting_measurement : public measurement
+    {
+    public:
+        counting_measurement(camera* cam, std::uint64_t* nan_count) : cam_{cam}, nan_count_{nan_count} {}
+
+        std::optional<measurement_sample_p_and_wi_result> sample_p_and_wi(vector2 const& a, vector2 const& b, allocator_wrapper& al) const override
+        {
+            return cam_->sample_p_and_wi(a, b, al);
+        }
+        std::optional<measurement_sample_p> sample_p(surface_point const& v, vector2 const& s, allocator_wrapper& al) const override
+        {
+            return cam_->sample_p(v, s, al);
+        }
+        std::optional<measurement_sample_p> sample_p(vector3 const& wi, vector2 const& s, allocator_wrapper& al) const override
+        {
+            return cam_->sample_p(wi, s, al);
+        }
+        double pdf_wi(surface_point const& p, vector3 const& wi) const override { return cam_->pdf_wi(p, wi); }
+        void add_sample(surface_point const& p, vector3 Li) const override
+        {
+            if(std::isinf(Li.x) || std::isinf(Li.y) || std::isinf(Li.z) || std::isnan(Li.x) || std::isnan(Li.y) || std::isnan(Li.z))
+            {
+                *nan_count_ += 1;
+                Li = {0.0, 0.0, 0.0};  // same replacement the camera makes, without its std::cout line
+            }
+            cam_->add_sample(p, Li);
+        }
+        void add_sample_count(int value) const override { cam_->add_sample_count(value); }
+
+    private:
+        camera* cam_{};
+        std::uint64_t* nan_count_{};
+    };
+
+    // ---------------------------------------------------------------- scene construction
+    struct in_memory_mesh
+    {
+        std::shared_ptr<mesh> m{};
+    };
+
+    vector3 v3(double const* p) { return {p[0], p[1], p[2]}; }
+
+    struct ref_scene
+    {
+        shared_state shared{};
+        wrapping_accel const* accel{};
+        std::shared_ptr<entity_scene> scene{};
+        std::vector<std::shared_ptr<surface>> surfaces{};
+        std::vector<std::shared_ptr<material>> materials{};
+        std::vector<std::shared_ptr<medium>> media{};
+        fcgpu_camera camera{};
+        std::uint32_t primitive_total{};
+    };
+
+    std::shared_ptr<material> make_material(fcgpu_material const& m)
+    {
+        auto rgb = [](double const* c) { return std::make_shared<const_texture_2d_rgb>(vector3{c[0], c[1], c[2]}); };
+        auto rg = [](double const* c) { return std::make_shared<const_texture_2d_rg>(vector2{c[0], c[1]}); };
+        auto r = [](double c) { return std::make_shared<const_texture_2d_r>(c); };
+        switch(m.kind)
+        {
+        case FCGPU_MATERIAL_DIFFUSE:
+            return std::make_shared<diffuse_material>(rgb(m.color_a), nullptr);
+        case FCGPU_MATERIAL_MIRROR:
+            return std::make_shared<mirror_material>(rgb(m.color_a), rg(m.roughness));
+        case FCGPU_MATERIAL_GLASS:
+            return std::make_shared<glass_material>(rgb(m.color_a), rgb(m.color_b), rg(m.roughness));
+        case FCGPU_MATERIAL_PLASTIC:
+            return std::make_shared<plastic_material>(rgb(m.color_a), rgb(m.color_b), rg(m.roughness), r(m.ior));
+        case FCGPU_MATERIAL_STANDARD:
+            return std::make_shared<standard_material>(rgb(m.color_a), r(m.metalness), r(m.roughness[0]), r(m.ior), nullptr);
+        case FCGPU_MATERIAL_TRANSMISSION:
+            return std::make_shared<transmission_material>(rgb(m.color_b), rg(m.roughness));
+        default:
+            return nullptr;
+        }
+    }
+
+    std::shared_ptr<surface> make_surface(fcgpu_scene_desc const& d, fcgpu_surface const& s)
+    {
+        switch(s.kind)
+        {
+        case FCGPU_SURFACE_SPHERE:
+            return std::make_shared<sphere_surface>(pr_transform{v3(s.position), v3(s.rotation)}, s.radius);
+        case FCGPU_SURFACE_PLANE:
+            return std::make_shared<plane_surface>(pr_transform{v3(s.position), v3(s.rotation)}, vector2{s.size[0], s.size[1]});
+        case FCGPU_SURFACE_MESH:
+        {
+            std::unique_ptr<vector3f[]> positions{new vector3f[s.vertex_count]};
+            std::unique_ptr<vector3f[]> normals{};
+            std::unique_ptr<vector2f[]> uvs{};
+            for(std::uint32_t i{}; i < s.vertex_count; ++i)
+            {
+                float const* p{d.positions + 3 * static_cast<std::size_t>(s.vertex_offset + i)};
+                positions[i] = vector3f{p[0], p[1], p[2]};
+            }
+            if(s.has_normals)
+            {
+                normals.reset(new vector3f[s.vertex_count]);
+                for(std::uint32_t i{}; i < s.vertex_count; ++i)
+                {
+                    float const* p{d.normals + 3 * static_cast<std::size_t>(s.vertex_offset + i)};
+                    normals[i] = vector3f{p[0], p[1], p[2]};
+                }
+            }
+            if(s.has_uvs)
+            {
+                uvs.reset(new vector2f[s.vertex_count]);
+                for(std::uint32_t i{}; i < s.vertex_count; ++i)
+                {
+                    float const* p{d.uvs + 2 * static_cast<std::size_t>(s.vertex_offset + i)};
+                    uvs[i] = vector2f{p[0], p[1]};
+                }
+            }
+            std::unique_ptr<std::uint32_t[]> indices{new std::uint32_t[s.index_count]};
+            std::memcpy(indices.get(), d.indices + s.index_offset, sizeof(std::uint32_t) * s.index_count);
+            auto m{std::make_shared<default_mesh>(s.vertex_count, std::move(positions), std::move(normals), std::move(uvs), s.index_count, std::move(indices))};
+            return std::make_shared<mesh_surface>(prs_transform{v3(s.position), v3(s.rotation), v3(s.scale)}, m);
+        }
+        default:
+            return nullptr;
+        }
+    }
+
+    struct render_worker
+    {
+        std::shared_ptr<render_target> target{};
+        std::unique_ptr<camera> cam{};
+        std::uint64_t nan_count{};
+    };
+}
+
+extern "C"
+{
+    struct fcref_stats
+    {
+        std::uint64_t closest_rays;
+        std::uint64_t any_rays;
+        std::uint64_t any_occluded;
+        std::uint64_t nan_samples;
+        std::uint64_t samples;
+        double seconds;
+    };
+
+    void* fcref_scene_create(fcgpu_scene_desc const* d)
+    {
+        auto* rs{new ref_scene{}};
+        rs->camera = d->camera;
+
+        for(std::uint32_t i{}; i < d->surface_count; ++i)
+        {
+            rs->surfaces.push_back(make_surface(*d, d->surfaces[i]));
+            if(rs->surfaces.back() == nullptr) { delete rs; return nullptr; }
+        }
+        for(std::uint32_t i{}; i < d->material_count; ++i)
+        {
+            rs->materials.push_back(make_material(d->materials[i]));
+            if(rs->materials.back() == nullptr) { delete rs; return nullptr; }
+        }
+        for(std::uint32_t i{}; i < d->medium_count; ++i)
+        {
+            auto const& m{d->media[i]};
+            rs->media.push_back(std::make_shared<uniform_medium>(m.priority, m.ior, v3(m.color), m.density));
+        }
+
+        std::vector<entity> entities{};
+        std::uint32_t offset{};
+        for(std::uint32_t i{}; i < d->entity_count; ++i)
+        {
+            auto const& e{d->entities[i]};
+            entity ent{};
+            ent.surface = rs->surfaces[e.surface];
+            ent.material = rs->materials[e.material];
+            if(e.emissive)
+            {
+                ent.area_light = std::make_shared<const_diffuse_area_light>(ent.surface.get(), v3(e.emission_color), e.emission_strength);
+            }
+            if(e.medium >= 0) ent.medium = rs->media[e.medium];
+            rs->shared.prim_offset.push_back(offset);
+            offset += ent.surface->get_primitive_count();
+            entities.push_back(std::move(ent));
+        }
+        rs->primitive_total = offset;
+
+        std::shared_ptr<infinity_area_light> env{};
+        if(d->env_kind == FCGPU_ENV_CONST)
+        {
+            env = std::make_shared<const_infinity_area_light>(v3(d->env_color), 1.0);
+        }
+
+        wrapping_accel_factory factory{&rs->shared, &rs->accel};
+        uniform_light_distribution_factory uldf{};
+        uniform_spatial_light_distribution_factory usldf{};
+        rs->scene = std::make_shared<entity_scene>(std::move(entities), env, factory, uldf, usldf);
+        return rs;
+    }
+
+    void fcref_scene_destroy(void* scene) { delete static_cast<ref_scene*>(scene); }
+
+    std::uint32_t fcref_primitive_count(void* scene) { return static_cast<ref_scene*>(scene)->primitive_total; }
+
+    // Renders samples [sample_begin, sample_begin+sample_count) of every pixel of the tile.
+    // rgb_sum (W*H*3 doubles, may be NULL) receives the SUM over workers of
+    // render_target::get_pixel_sample_sum, total_count the sum of get_sample_count -- the two
+    // quantities renderer::export_image divides (renderer.hpp:118-135). Values are ADDED to
+    // whatever rgb_sum holds so passes can be accumulated.
+    int fcref_render(void* scene_ptr, int integrator_kind, int max_path_length, int visible_inf, std::uint64_t seed,
+                     std::uint32_t sample_begin, std::uint32_t sample_count, int x0, int y0, int w, int h, int threads,
+                     double* rgb_sum, std::uint64_t* total_count, fcref_stats* stats, ray_record* ray_log, std::uint64_t ray_log_capacity,
+                     std::uint64_t* ray_log_size)
+    {
+        auto* rs{static_cast<ref_scene*>(scene_ptr)};
+        std::shared_ptr<integrator> integ{};
+        if(integrator_kind == FCGPU_INTEGRATOR_MIS)
+            integ.reset(new forward_mis_integrator{max_path_length, visible_inf != 0});
+        else
+            integ.reset(new forward_bsdf_integrator{max_path_length});
+
+        vector2i resolution{rs->camera.width, rs->camera.height};
+        perspective_camera_factory cam_factory{pr_transform{v3(rs->camera.position), v3(rs->camera.rotation)}, rs->camera.fov, rs->camera.lens_radius, rs->camera.focus_distance};
+
+        std::vector<ray_record> log{};
+        if(ray_log != nullptr) threads = 1;
+        threads = std::max(1, threads);
+
+        rs->shared.count = stats != nullptr;
+        rs->shared.closest_rays = 0;
+        rs->shared.any_rays = 0;
+        rs->shared.any_occluded = 0;
+        rs->shared.log = ray_log != nullptr ? &log : nullptr;
+
+        std::vector<render_worker> workers(threads);
+        for(auto& wk : workers)
+        {
+            wk.target.reset(new render_target{resolution});
+            wk.cam = cam_factory.create(wk.target);
+        }
+
+        std::atomic<int> next_pixel{};
+        int pixel_total{w * h};
+        auto start{std::chrono::steady_clock::now()};
+
+        auto body = [&](int index)
+        {
+            // renderer::worker_thread, renderer.hpp:154-179
+            paged_allocator pages{1024 * 1024};
+            allocator_wrapper sample_allocator{&pages};
+            counter_sampler sampler{static_cast<int>(sample_count), seed};
+            render_worker& wk{workers[index]};
+            counting_measurement meas{wk.cam.get(), &wk.nan_count};
+            while(true)
+            {
+                int idx{next_pixel.fetch_add(1, std::memory_order_relaxed)};
+                if(idx >= pixel_total) break;
+                vector2i pixel{x0 + idx % w, y0 + idx / w};
+                wk.cam->set_pixel(pixel);
+                for(std::uint32_t s{}; s < sample_count; ++s)
+                {
+                    sampler.set_sample(pixel, static_cast<int>(sample_begin + s));
+                    integ->run_once(meas, *rs->scene, sampler, sample_allocator);
+                    sample_allocator.clear();
+                }
+            }
+        };
+
+        if(threads == 1)
+        {
+            body(0);
+        }
+        else
+        {
+            std::vector<std::thread> pool{};
+            for(int i{}; i < threads; ++i) pool.emplace_back(body, i);
+            for(auto& t : pool) t.join();
+        }
+        double seconds{std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count()};
+
+        std::uint64_t count{};
+        std::uint64_t nan_count{};
+        for(auto& wk : workers)
+        {
+            count += wk.target->get_sample_count();
+            nan_count += wk.nan_count;
+        }
+        if(rgb_sum != nullptr)
+        {
+            for(int y{y0}; y < y0 + h; ++y)
+                for(int x{x0}; x < x0 + w; ++x)
+                {
+                    vector3 c{};
+                    for(auto& wk : workers) c += wk.target->get_pixel_sample_sum({x, y});
+                    double* out{rgb_sum + 3 * (static_cast<std::size_t>(y) * resolution.x + x)};
+                    out[0] += c.x; out[1] += c.y; out[2] += c.z;
+                }
+        }
+        if(total_count != nullptr) *total_count += count;
+        if(stats != nullptr)
+        {
+            stats->closest_rays = rs->shared.closest_rays;
+            stats->any_rays = rs->shared.any_rays;
+            stats->any_occluded = rs->shared.any_occluded;
+            stats->nan_samples = nan_count;
+            stats->samples = count;
+            stats->seconds = seconds;
+        }
+        if(ray_log != nullptr)
+        {
+            std::uint64_t n{std::min<std::uint64_t>(log.size(), ray_log_capacity)};
+            std::memcpy(ray_log, log.data(), n * sizeof(ray_record));
+            if(ray_log_size != nullptr) *ray_log_size = log.size();
+        }
+        rs->shared.count = false;
+        rs->shared.log = nullptr;
+        return 0;
+    }
+
+    // closest-hit through the reference's BVH (brute_force = 0) or its brute-force structure
+    int fcref_trace_closest(void* scene_ptr, std::uint64_t n, fcgpu_ray const* rays, fcgpu_hit* hits, int brute_force)
+    {
+        auto* rs{static_cast<ref_scene*>(scene_ptr)};
+        acceleration_structure const& accel{brute_force ? rs->accel->brute() : rs->accel->bvh()};
+        paged_allocator pages{1024 * 1024};
+        allocator_wrapper al{&pages};
+        for(std::uint64_t i{}; i < n; ++i)
+        {
+            ray3 ray{v3(rays[i].origin), v3(rays[i].direction)};
+            auto r{accel.raycast_surface_point(ray, rays[i].t_max, al)};
+            fcgpu_hit& h{hits[i]};
+            h = fcgpu_hit{};
+            if(r)
+            {
+                h.prim = rs->shared.prim_id(r->entity_primitive);
+                h.t = dot(r->p->get_position() - ray.origin, ray.direction) / dot(ray.direction, ray.direction);
+            }
+            else
+            {
+                h.prim = ~0u;
+                h.t = std::numeric_limits<double>::infinity();
+            }
+            al.clear();
+        }
+        return 0;
+    }
+
+    int fcref_trace_any(void* scene_ptr, std::uint64_t n, fcgpu_ray const* rays, std::uint8_t* occluded, int brute_force)
+    {
+        auto* rs{static_cast<ref_scene*>(scene_ptr)};
+        acceleration_structure const& accel{brute_force ? rs->accel->brute() : rs->accel->bvh()};
+        for(std::uint64_t i{}; i < n; ++i)
+        {
+            ray3 ray{v3(rays[i].origin), v3(rays[i].direction)};
+            occluded[i] = accel.raycast(ray, rays[i].t_max) ? 1 : 0;
+        }
+        return 0;
+    }
+
+    // Per-lobe tables: material::evaluate on a synthetic hit (geometric normal ng, shading frame
+    // t/ns/b, uv 0), then for query i: lobe = bsdf::sample_bxdf(u_lobe[i]);
+    //   f[i]     = bsdf::evaluate(lobe, wo[i], wi[i], eta_a, eta_b)
+    //   pdf[i]   = bsdf::pdf_wi(...)
+    //   sample   = bsdf::sample_wi(lobe, wo[i], eta_a, eta_b, u1[i], u2[i]) -> ok, wi, value, pdf
+    struct fcref_bsdf_query
+    {
+        double wo[3];
+        double wi[3];
+        double u_lobe;
+        double u1[2];
+        double u2[2];
+    };
+    struct fcref_bsdf_result
+    {
+        double f[3];
+        double pdf;
+        double s_wi[3];
+        double s_value[3];
+        double s_pdf;
+        std::int32_t lobe;
+        std::int32_t is_delta;
+        std::int32_t s_ok;
+        std::int32_t reserved;
+    };
+
+    int fcref_bsdf_table(fcgpu_material const* m, double const* ng, double const* tangent, double const* ns, double const* bitangent,
+                         double eta_a, double eta_b, std::uint64_t n, fcref_bsdf_query const* q, fcref_bsdf_result* out)
+    {
+        auto mat{make_material(*m)};
+        if(mat == nullptr) return -1;
+        paged_allocator pages{1024 * 1024};
+        allocator_wrapper al{&pages};
+        for(std::uint64_t i{}; i < n; ++i)
+        {
+            surface_point p{};
+            p.set_normal(v3(ng));
+            p.set_shading_tangent(v3(tangent));
+            p.set_shading_normal(v3(ns));
+            p.set_shading_bitangent(v3(bitangent));
+            bsdf const* b{mat->evaluate(p, al)};
+            int lobe{b->sample_bxdf(q[i].u_lobe)};
+            fcref_bsdf_result& r{out[i]};
+            r = fcref_bsdf_result{};
+            r.lobe = lobe;
+            r.is_delta = b->get_type(lobe) == bxdf_type::delta ? 1 : 0;
+            vector3 wo{v3(q[i].wo)};
+            vector3 wi{v3(q[i].wi)};
+            vector3 f{b->evaluate(lobe, wo, wi, eta_a, eta_b)};
+            r.f[0] = f.x; r.f[1] = f.y; r.f[2] = f.z;
+            r.pdf = b->pdf_wi(lobe, wo, wi, eta_a, eta_b);
+            vector3 swi{};
+            vector3 value{};
+            double pdf{};
+            auto ok{b->sample_wi(lobe, wo, eta_a, eta_b, vector2{q[i].u1[0], q[i].u1[1]}, vector2{q[i].u2[0], q[i].u2[1]}, &swi, &value, &pdf)};
+            r.s_ok = ok == sample_result::success ? 1 : 0;
+            if(r.s_ok)
+            {
+                r.s_wi[0] = swi.x; r.s_wi[1] = swi.y; r.s_wi[2] = swi.z;
+                r.s_value[0] = value.x; r.s_value[1] = value.y; r.s_value[2] = value.z;
+                r.s_pdf = pdf;
+            }
+            al.clear();
+        }
+        return 0;
+    }
+
+    std::uint64_t fcref_ray_record_size() { return sizeof(ray_record); }
+}

@@ -1,0 +1,115 @@
+"""ctypes mirror of include/fcgpu.h (the C-ABI boundary). Plain data only; no compute here."""
+import ctypes as C
+
+c_double3 = C.c_double * 3
+c_double2 = C.c_double * 2
+
+SURFACE_SPHERE, SURFACE_PLANE, SURFACE_MESH = 0, 1, 2
+MATERIAL_DIFFUSE, MATERIAL_MIRROR, MATERIAL_GLASS = 0, 1, 2
+MATERIAL_PLASTIC, MATERIAL_STANDARD, MATERIAL_TRANSMISSION = 3, 4, 5
+ENV_NONE, ENV_CONST = 0, 1
+PRECISION_F32, PRECISION_F64 = 0, 1
+INTEGRATOR_BSDF, INTEGRATOR_MIS = 0, 1
+
+E_INVALID, E_HIP, E_NOSCENE, E_LIMIT, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+
+
+class Surface(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("has_normals", C.c_int32), ("has_uvs", C.c_int32), ("reserved", C.c_int32),
+        ("position", c_double3), ("rotation", c_double3), ("scale", c_double3),
+        ("radius", C.c_double), ("size", c_double2),
+        ("vertex_offset", C.c_uint32), ("vertex_count", C.c_uint32),
+        ("index_offset", C.c_uint32), ("index_count", C.c_uint32),
+    ]
+
+
+class Material(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("reserved", C.c_int32),
+        ("color_a", c_double3), ("color_b", c_double3), ("roughness", c_double2),
+        ("ior", C.c_double), ("metalness", C.c_double),
+    ]
+
+
+class Medium(C.Structure):
+    _fields_ = [
+        ("priority", C.c_int32), ("reserved", C.c_int32),
+        ("ior", C.c_double), ("color", c_double3), ("density", C.c_double),
+    ]
+
+
+class Entity(C.Structure):
+    _fields_ = [
+        ("surface", C.c_int32), ("material", C.c_int32), ("medium", C.c_int32), ("emissive", C.c_int32),
+        ("emission_color", c_double3), ("emission_strength", C.c_double),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("position", c_double3), ("rotation", c_double3),
+        ("fov", C.c_double), ("lens_radius", C.c_double), ("focus_distance", C.c_double),
+        ("width", C.c_int32), ("height", C.c_int32),
+    ]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("surfaces", C.POINTER(Surface)), ("materials", C.POINTER(Material)),
+        ("media", C.POINTER(Medium)), ("entities", C.POINTER(Entity)),
+        ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
+        ("uvs", C.POINTER(C.c_float)), ("indices", C.POINTER(C.c_uint32)),
+        ("surface_count", C.c_uint32), ("material_count", C.c_uint32),
+        ("medium_count", C.c_uint32), ("entity_count", C.c_uint32),
+        ("vertex_total", C.c_uint32), ("index_total", C.c_uint32),
+        ("env_kind", C.c_int32), ("reserved", C.c_int32),
+        ("env_color", c_double3),
+        ("camera", Camera),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("precision", C.c_int32), ("sort_materials", C.c_int32), ("epsilon", C.c_double),
+        ("max_paths_in_flight", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class Tile(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+
+class Ray(C.Structure):
+    _fields_ = [("origin", c_double3), ("direction", c_double3), ("t_max", C.c_double)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("t", C.c_double), ("b0", C.c_double), ("b1", C.c_double),
+                ("prim", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+        ("shadow_occluded", C.c_uint64), ("nan_samples", C.c_uint64), ("stack_overflows", C.c_uint64),
+        ("bvh_nodes", C.c_uint64), ("primitives", C.c_uint64), ("kernel_launches", C.c_uint64),
+        ("reserved", C.c_uint64 * 7),
+    ]
+
+
+# numpy dtypes with the same layout as Ray / Hit (for bulk ray sets)
+import numpy as _np
+
+ray_dtype = _np.dtype([("origin", "<f8", 3), ("direction", "<f8", 3), ("t_max", "<f8")])
+hit_dtype = _np.dtype([("t", "<f8"), ("b0", "<f8"), ("b1", "<f8"), ("prim", "<u4"), ("reserved", "<u4")])
+assert ray_dtype.itemsize == C.sizeof(Ray) and hit_dtype.itemsize == C.sizeof(Hit)
+
+# every symbol include/fcgpu.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "fcgpu_create", "fcgpu_destroy", "fcgpu_last_error", "fcgpu_set_options", "fcgpu_upload_scene",
+    "fcgpu_set_sampler", "fcgpu_render_pass", "fcgpu_trace_closest", "fcgpu_trace_any",
+    "fcgpu_trace_closest_device", "fcgpu_trace_any_device", "fcgpu_clear_film", "fcgpu_read_film",
+    "fcgpu_film_device_ptr", "fcgpu_add_sample_count", "fcgpu_get_counters", "fcgpu_reset_counters",
+    "fcgpu_sync", "fcgpu_stream", "fcgpu_export_image", "fcgpu_version",
+]

@@ -1,0 +1,369 @@
+"""Scene descriptions (plain data) for the C-ABI of include/fcgpu.h.
+
+The reference's room scene (src/example_scenes.hpp:187-263) loads three meshes (`walls`,
+`lights_1`, `lights_2`) that are NOT in the reference repository (assets/ is git-ignored), so
+`room()` authors a documented procedural stand-in for them; spheres, materials, the medium, the
+emitter strength and the camera are the reference's values verbatim.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi as A
+
+
+class Scene:
+    """Mutable builder; `desc()` freezes it into a ctypes fcgpu_scene_desc (arrays kept alive)."""
+
+    def __init__(self):
+        self.surfaces, self.materials, self.media, self.entities = [], [], [], []
+        self._pos, self._nrm, self._uv, self._idx = [], [], [], []
+        self._nvert = 0
+        self._nidx = 0
+        self.camera = A.Camera()
+        self.env_kind = A.ENV_NONE
+        self.env_color = (0.0, 0.0, 0.0)
+        self._keep = None
+
+    # ---- surfaces
+    def sphere(self, position, radius, rotation=(0, 0, 0)):
+        s = A.Surface(kind=A.SURFACE_SPHERE, radius=radius)
+        s.position[:] = position
+        s.rotation[:] = rotation
+        s.scale[:] = (1, 1, 1)
+        self.surfaces.append(s)
+        return len(self.surfaces) - 1
+
+    def plane(self, position, size, rotation=(0, 0, 0)):
+        s = A.Surface(kind=A.SURFACE_PLANE)
+        s.position[:] = position
+        s.rotation[:] = rotation
+        s.scale[:] = (1, 1, 1)
+        s.size[:] = size
+        self.surfaces.append(s)
+        return len(self.surfaces) - 1
+
+    def mesh(self, positions, indices, normals=None, uvs=None, position=(0, 0, 0), rotation=(0, 0, 0), scale=(1, 1, 1)):
+        positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        assert indices.size % 3 == 0 and (indices.size == 0 or indices.max() < len(positions))
+        s = A.Surface(kind=A.SURFACE_MESH, has_normals=int(normals is not None), has_uvs=int(uvs is not None))
+        s.position[:] = position
+        s.rotation[:] = rotation
+        s.scale[:] = scale
+        s.vertex_offset, s.vertex_count = self._nvert, len(positions)
+        s.index_offset, s.index_count = self._nidx, indices.size
+        self._pos.append(positions)
+        self._nrm.append(np.zeros_like(positions) if normals is None else
+                         np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3))
+        self._uv.append(np.zeros((len(positions), 2), np.float32) if uvs is None else
+                        np.ascontiguousarray(uvs, dtype=np.float32).reshape(-1, 2))
+        self._idx.append(indices)
+        self._nvert += len(positions)
+        self._nidx += indices.size
+        self.surfaces.append(s)
+        return len(self.surfaces) - 1
+
+    # ---- materials / media
+    def material(self, kind, color_a=(0, 0, 0), color_b=(0, 0, 0), roughness=(0, 0), ior=1.0, metalness=0.0):
+        m = A.Material(kind=kind, ior=ior, metalness=metalness)
+        m.color_a[:] = color_a
+        m.color_b[:] = color_b
+        m.roughness[:] = roughness
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def diffuse(self, reflectance):
+        return self.material(A.MATERIAL_DIFFUSE, color_a=reflectance)
+
+    def mirror(self, reflectance, roughness):
+        return self.material(A.MATERIAL_MIRROR, color_a=reflectance, roughness=roughness)
+
+    def glass(self, reflectance, transmittance, roughness):
+        return self.material(A.MATERIAL_GLASS, color_a=reflectance, color_b=transmittance, roughness=roughness)
+
+    def plastic(self, diffuse, specular, roughness, ior):
+        return self.material(A.MATERIAL_PLASTIC, color_a=diffuse, color_b=specular, roughness=roughness, ior=ior)
+
+    def standard(self, base_color, metalness, roughness, ior):
+        return self.material(A.MATERIAL_STANDARD, color_a=base_color, roughness=(roughness, roughness), ior=ior,
+                             metalness=metalness)
+
+    def transmission(self, transmittance, roughness):
+        return self.material(A.MATERIAL_TRANSMISSION, color_b=transmittance, roughness=roughness)
+
+    def medium(self, priority, ior, color, density):
+        m = A.Medium(priority=priority, ior=ior, density=density)
+        m.color[:] = color
+        self.media.append(m)
+        return len(self.media) - 1
+
+    def entity(self, surface, material, medium=-1, emission=None, strength=0.0):
+        e = A.Entity(surface=surface, material=material, medium=medium, emissive=int(emission is not None),
+                     emission_strength=strength)
+        e.emission_color[:] = emission if emission is not None else (0, 0, 0)
+        self.entities.append(e)
+        return len(self.entities) - 1
+
+    def set_camera(self, position, rotation, fov, width, height, lens_radius=0.0, focus_distance=0.0):
+        c = self.camera
+        c.position[:] = position
+        c.rotation[:] = rotation
+        c.fov, c.lens_radius, c.focus_distance = fov, lens_radius, focus_distance
+        c.width, c.height = width, height
+
+    def set_env(self, color):
+        self.env_kind = A.ENV_CONST
+        self.env_color = tuple(color)
+
+    # ---- queries
+    def primitive_counts(self):
+        out = []
+        for e in self.entities:
+            s = self.surfaces[e.surface]
+            out.append(s.index_count // 3 if s.kind == A.SURFACE_MESH else 1)
+        return out
+
+    def primitive_total(self):
+        return sum(self.primitive_counts())
+
+    def desc(self):
+        d = A.SceneDesc()
+        surf = (A.Surface * max(1, len(self.surfaces)))(*self.surfaces)
+        mats = (A.Material * max(1, len(self.materials)))(*self.materials)
+        meds = (A.Medium * max(1, len(self.media)))(*self.media)
+        ents = (A.Entity * max(1, len(self.entities)))(*self.entities)
+        pos = np.concatenate(self._pos) if self._pos else np.zeros((1, 3), np.float32)
+        nrm = np.concatenate(self._nrm) if self._nrm else np.zeros((1, 3), np.float32)
+        uv = np.concatenate(self._uv) if self._uv else np.zeros((1, 2), np.float32)
+        idx = np.concatenate(self._idx) if self._idx else np.zeros((3,), np.uint32)
+        pos, nrm, uv, idx = (np.ascontiguousarray(a) for a in (pos, nrm, uv, idx))
+        d.surfaces, d.materials, d.media, d.entities = surf, mats, meds, ents
+        d.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
+        d.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))
+        d.uvs = uv.ctypes.data_as(C.POINTER(C.c_float))
+        d.indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.surface_count, d.material_count = len(self.surfaces), len(self.materials)
+        d.medium_count, d.entity_count = len(self.media), len(self.entities)
+        d.vertex_total, d.index_total = self._nvert, self._nidx
+        d.env_kind = self.env_kind
+        d.env_color[:] = self.env_color
+        d.camera = self.camera
+        self._keep = (surf, mats, meds, ents, pos, nrm, uv, idx)
+        return d
+
+
+# --------------------------------------------------------------------------- mesh helpers
+def grid_quad(origin, du, dv, nu, nv):
+    """(nu x nv) quads spanning origin + s*du + t*dv, s,t in [0,1]; normal = cross(du, dv)."""
+    origin, du, dv = (np.asarray(a, np.float64) for a in (origin, du, dv))
+    s, t = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+    p = origin + s[..., None] * du + t[..., None] * dv
+    p = p.reshape(-1, 3)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    a = (i * (nv + 1) + j).reshape(-1)
+    b = a + (nv + 1)
+    c = b + 1
+    d = a + 1
+    tris = np.stack([a, b, c, a, c, d], axis=1).reshape(-1)
+    return p.astype(np.float32), tris.astype(np.uint32)
+
+
+def merge(parts):
+    pos, idx, off = [], [], 0
+    for p, i in parts:
+        pos.append(p)
+        idx.append(i + off)
+        off += len(p)
+    return np.concatenate(pos), np.concatenate(idx).astype(np.uint32)
+
+
+def box_inward(lo, hi, n, faces="xXyYzZ"):
+    """Axis-aligned box whose faces (subset `faces`) face the INSIDE; each face n x n quads."""
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    ex, ey, ez = (hi - lo) * np.eye(3)
+    parts = []
+    if "y" in faces:  # floor, normal +y = cross(dz, dx)
+        parts.append(grid_quad(lo, ez, ex, n, n))
+    if "Y" in faces:  # ceiling, normal -y = cross(dx, dz)
+        parts.append(grid_quad(lo + ey, ex, ez, n, n))
+    if "x" in faces:  # x = lo wall, normal +x = cross(dy, dz)
+        parts.append(grid_quad(lo, ey, ez, n, n))
+    if "X" in faces:  # x = hi wall, normal -x = cross(dz, dy)
+        parts.append(grid_quad(lo + ex, ez, ey, n, n))
+    if "z" in faces:  # z = lo wall, normal +z = cross(dx, dy)
+        parts.append(grid_quad(lo, ex, ey, n, n))
+    if "Z" in faces:  # z = hi wall, normal -z = cross(dy, dx)
+        parts.append(grid_quad(lo + ez, ey, ex, n, n))
+    return merge(parts)
+
+
+def box_outward(lo, hi, faces="xXyYzZ"):
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    ex, ey, ez = (hi - lo) * np.eye(3)
+    parts = []
+    if "y" in faces:
+        parts.append(grid_quad(lo, ex, ez, 1, 1))
+    if "Y" in faces:
+        parts.append(grid_quad(lo + ey, ez, ex, 1, 1))
+    if "x" in faces:
+        parts.append(grid_quad(lo, ez, ey, 1, 1))
+    if "X" in faces:
+        parts.append(grid_quad(lo + ex, ey, ez, 1, 1))
+    if "z" in faces:
+        parts.append(grid_quad(lo, ey, ex, 1, 1))
+    if "Z" in faces:
+        parts.append(grid_quad(lo + ez, ex, ey, 1, 1))
+    return merge(parts)
+
+
+# --------------------------------------------------------------------------- the room
+ROOM_LO, ROOM_HI = (-12.0, 0.0, -10.0), (12.0, 8.0, 20.0)
+ROOM_LIGHTS = [(x, z) for z in (-2.0, 10.0) for x in (-7.5, -2.5, 2.5, 7.5)]
+
+CENTER_MATERIALS = ("rough_glass", "smooth_glass", "diffuse", "plastic", "rough_mirror", "smooth_mirror",
+                    "smooth_plastic", "standard", "transmission")
+
+
+def room(width=1920, height=1080, tess=64, center="rough_glass", env=None):
+    """Stand-in for example_scenes.hpp:187-263.
+
+    Verbatim from the reference: the three spheres (:218-242), their materials, the medium
+    (priority 1, ior 1.45, colour (0.6,0.2,0.8), density 0.5), emitter (1,1,1) x 250 (:215),
+    wall albedo 0.8 (:195), fixture albedo 0.1 (:203,:212), camera (:250).
+    Invented (the meshes are absent): `walls` = closed box ROOM_LO..ROOM_HI, each face
+    tess x tess quads (12*tess^2 triangles); `lights_2` = eight 0.5 x 0.5 downward quads at
+    y = 7.88; `lights_1` = open fixture boxes (no top face) around them, y in [7.9, 8].
+    `center` swaps the middle sphere's material for the material sweep (BASELINE config 3).
+    """
+    sc = Scene()
+    wp, wi = box_inward(ROOM_LO, ROOM_HI, tess)
+    walls = sc.mesh(wp, wi)
+    fixtures = merge([box_outward((x - 0.4, 7.9, z - 0.4), (x + 0.4, 8.0, z + 0.4), faces="xXyzZ")
+                      for x, z in ROOM_LIGHTS])
+    lights_1 = sc.mesh(*fixtures)
+    quads = merge([grid_quad((x - 0.25, 7.88, z - 0.25), (0.5, 0, 0), (0, 0, 0.5), 1, 1) for x, z in ROOM_LIGHTS])
+    lights_2 = sc.mesh(*quads)
+
+    sc.entity(walls, sc.diffuse((0.8, 0.8, 0.8)))
+    sc.entity(lights_1, sc.diffuse((0.1, 0.1, 0.1)))
+    sc.entity(lights_2, sc.diffuse((0.1, 0.1, 0.1)), emission=(1.0, 1.0, 1.0), strength=250.0)
+
+    sc.entity(sc.sphere((4.2, 2.01, 0.0), 2.0), sc.diffuse((0.2, 0.4, 0.8)))
+
+    mid = sc.sphere((0.0, 2.01, 0.0), 2.0)
+    med = -1
+    if center == "rough_glass":
+        mat = sc.glass((1, 1, 1), (1, 1, 1), (0.3, 0.3))
+        med = sc.medium(1, 1.45, (0.6, 0.2, 0.8), 0.5)
+    elif center == "smooth_glass":
+        mat = sc.glass((1, 1, 1), (1, 1, 1), (0.0, 0.0))
+        med = sc.medium(1, 1.45, (0.6, 0.2, 0.8), 0.5)
+    elif center == "diffuse":
+        mat = sc.diffuse((0.8, 0.6, 0.2))
+    elif center == "plastic":
+        mat = sc.plastic((0.8, 0.6, 0.2), (1, 1, 1), (0.15, 0.15), 1.45)
+    elif center == "smooth_plastic":
+        mat = sc.plastic((0.8, 0.6, 0.2), (1, 1, 1), (0.0, 0.0), 1.45)
+    elif center == "rough_mirror":
+        mat = sc.mirror((0.8, 0.8, 0.8), (0.2, 0.2))
+    elif center == "smooth_mirror":
+        mat = sc.mirror((0.8, 0.8, 0.8), (0.0, 0.0))
+    elif center == "standard":
+        mat = sc.standard((0.8, 0.5, 0.3), 0.6, 0.35, 1.45)
+    elif center == "transmission":
+        mat = sc.transmission((0.9, 0.9, 0.9), (0.25, 0.25))
+        med = sc.medium(1, 1.3, (0.2, 0.6, 0.8), 0.3)
+    else:
+        raise ValueError(center)
+    sc.entity(mid, mat, medium=med)
+
+    sc.entity(sc.sphere((-4.2, 2.01, 0.0), 2.0), sc.mirror((0.8, 0.4, 0.2), (0.2, 0.2)))
+
+    sc.set_camera((-7.23, 2.79, 16.37), (math.radians(-4.641), math.radians(157.552), 0.0), math.radians(35.0),
+                  width, height)
+    if env is not None:
+        sc.set_env(env)
+    return sc
+
+
+def room_planes(width=512, height=288):
+    """The 10-primitive stand-in SURVEY.md section 6 timed: 6 wall planes + 1 plane emitter + 3 spheres."""
+    sc = Scene()
+    white = sc.diffuse((0.8, 0.8, 0.8))
+    lo, hi = np.array(ROOM_LO), np.array(ROOM_HI)
+    cx, cy, cz = (lo + hi) / 2
+    sx, sy, sz = hi - lo
+    h = math.pi / 2
+    sc.entity(sc.plane((cx, lo[1], cz), (sx, sz)), white)                                  # floor
+    sc.entity(sc.plane((cx, hi[1], cz), (sx, sz), (math.pi, 0, 0)), white)                 # ceiling
+    sc.entity(sc.plane((lo[0], cy, cz), (sy, sz), (0, 0, -h)), white)                      # x = lo
+    sc.entity(sc.plane((hi[0], cy, cz), (sy, sz), (0, 0, h)), white)                       # x = hi
+    sc.entity(sc.plane((cx, cy, lo[2]), (sx, sy), (h, 0, 0)), white)                       # z = lo
+    sc.entity(sc.plane((cx, cy, hi[2]), (sx, sy), (-h, 0, 0)), white)                      # z = hi
+    sc.entity(sc.plane((0.0, 7.9, 4.0), (3.0, 3.0), (math.pi, 0, 0)), sc.diffuse((0.1, 0.1, 0.1)),
+              emission=(1, 1, 1), strength=250.0)
+    sc.entity(sc.sphere((4.2, 2.01, 0.0), 2.0), sc.diffuse((0.2, 0.4, 0.8)))
+    sc.entity(sc.sphere((0.0, 2.01, 0.0), 2.0), sc.glass((1, 1, 1), (1, 1, 1), (0.3, 0.3)),
+              medium=sc.medium(1, 1.45, (0.6, 0.2, 0.8), 0.5))
+    sc.entity(sc.sphere((-4.2, 2.01, 0.0), 2.0), sc.mirror((0.8, 0.4, 0.2), (0.2, 0.2)))
+    sc.set_camera((-7.23, 2.79, 16.37), (math.radians(-4.641), math.radians(157.552), 0.0), math.radians(35.0),
+                  width, height)
+    return sc
+
+
+def nested_media(width=256, height=256, smooth=True, env=(1.0, 1.0, 1.0)):
+    """Priority-media exercise in the spirit of scene_glass (example_scenes.hpp:101-185): a glass
+    shell (priority 2) holding water (priority 1) with an ice ball (priority 2) overlapping the
+    water surface, over a diffuse floor, lit by a constant environment and a sphere emitter."""
+    sc = Scene()
+    r = (0.0, 0.0) if smooth else (0.2, 0.2)
+    white = (1, 1, 1)
+    sc.entity(sc.plane((0, 0, 0), (30, 30)), sc.diffuse((0.5, 0.5, 0.5)))
+    sc.entity(sc.sphere((0, 2.0, 0), 2.0), sc.glass(white, white, r), medium=sc.medium(2, 1.52, (1, 1, 1), 1.0))
+    sc.entity(sc.sphere((0, 1.8, 0), 1.7), sc.glass(white, white, r), medium=sc.medium(1, 1.3614, (0.2, 0.6, 0.8), 1.0))
+    sc.entity(sc.sphere((0.4, 3.2, 0.2), 0.5), sc.glass(white, white, r), medium=sc.medium(2, 1.35, (0.2, 0.6, 0.8), 0.0))
+    sc.entity(sc.sphere((-3.5, 1.0, 1.0), 1.0), sc.plastic((0.8, 0.1, 0.05), white, (0.2, 0.2), 1.46))
+    sc.entity(sc.sphere((3.0, 5.0, -2.0), 0.7), sc.diffuse((0.1, 0.1, 0.1)), emission=(1, 0.9, 0.8), strength=30.0)
+    sc.set_camera((0.5, 3.5, -9.0), (math.radians(10.0), 0.0, 0.0), math.radians(40.0), width, height)
+    if env is not None:
+        sc.set_env(env)
+    return sc
+
+
+def primitives_zoo(width=128, height=128):
+    """All three surface kinds with rotations, a mesh with normals + uvs, every material class,
+    a mesh emitter and a plane emitter -- small, for exhaustive parity tests."""
+    sc = Scene()
+    sc.entity(sc.plane((0, 0, 0), (16, 16)), sc.diffuse((0.7, 0.7, 0.7)))
+    sc.entity(sc.plane((0, 4, -6), (16, 8), (math.radians(90), 0, 0)), sc.plastic((0.2, 0.6, 0.3), (1, 1, 1), (0.3, 0.1), 1.5))
+    # an icosphere-ish bumpy mesh with vertex normals and uvs
+    nu, nv = 12, 8
+    th, ph = np.meshgrid(np.linspace(0, math.pi, nv + 1), np.linspace(0, 2 * math.pi, nu + 1), indexing="ij")
+    rad = 1.0 + 0.08 * np.sin(3 * ph) * np.sin(2 * th)
+    p = np.stack([rad * np.sin(th) * np.cos(ph), rad * np.cos(th), rad * np.sin(th) * np.sin(ph)], -1).reshape(-1, 3)
+    nrm = p / np.maximum(np.linalg.norm(p, axis=1, keepdims=True), 1e-9)
+    uv = np.stack([ph / (2 * math.pi), th / math.pi], -1).reshape(-1, 2)
+    i, j = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    a = (i * (nu + 1) + j).reshape(-1)
+    b, c, d = a + (nu + 1), a + (nu + 2), a + 1
+    tris = np.stack([a, b, c, a, c, d], 1).reshape(-1)
+    sc.entity(sc.mesh(p, tris, normals=nrm, uvs=uv, position=(-2.5, 1.3, 0.5), rotation=(0.3, 0.5, 0.1), scale=(1.2, 1.0, 0.9)),
+              sc.standard((0.9, 0.6, 0.2), 0.7, 0.3, 1.45))
+    sc.entity(sc.sphere((0.5, 1.0, 1.0), 1.0, (0.2, 0.7, 0.4)), sc.glass((1, 1, 1), (1, 1, 1), (0.0, 0.0)),
+              medium=sc.medium(1, 1.5, (0.9, 0.4, 0.3), 0.4))
+    sc.entity(sc.sphere((3.0, 1.2, -0.5), 1.2), sc.mirror((0.9, 0.9, 0.9), (0.0, 0.0)))
+    sc.entity(sc.sphere((2.2, 0.6, 2.4), 0.6), sc.transmission((0.9, 0.9, 1.0), (0.2, 0.2)),
+              medium=sc.medium(1, 1.33, (0.3, 0.5, 0.9), 0.2))
+    bp, bi = box_outward((-0.5, 0.0, -0.5), (0.5, 1.0, 0.5))
+    sc.entity(sc.mesh(bp, bi, position=(-0.5, 0.0, 3.0), rotation=(0, 0.6, 0)), sc.mirror((0.7, 0.8, 0.9), (0.25, 0.1)))
+    qp, qi = grid_quad((-1.0, 5.0, -1.0), (2.0, 0, 0), (0, 0, 2.0), 2, 2)   # faces down
+    sc.entity(sc.mesh(qp, qi), sc.diffuse((0.1, 0.1, 0.1)), emission=(1.0, 0.95, 0.9), strength=20.0)
+    sc.entity(sc.plane((-4.0, 3.0, 2.0), (1.5, 1.5), (0, 0, math.radians(-110))), sc.diffuse((0.1, 0.1, 0.1)),
+              emission=(0.4, 0.6, 1.0), strength=15.0)
+    sc.set_camera((0.0, 3.2, 9.5), (math.radians(12.0), math.radians(180.0), 0.0), math.radians(42.0), width, height)
+    return sc
+
+
+BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo}
