@@ -63,7 +63,7 @@ typedef struct fcgpu_surface {
     uint32_t index_count;     /* multiple of 3; indices are relative to vertex_offset            */
 } fcgpu_surface;
 
-/* materials: src/materials/*.hpp. Round 1 carries constant textures only (const_texture_2d_*). */
+/* materials: the classes under src/materials/. Round 1 carries constant textures only (const_texture_2d_*). */
 #define FCGPU_MATERIAL_DIFFUSE 0       /* diffuse_material.hpp:18-38       color_a = reflectance               */
 #define FCGPU_MATERIAL_MIRROR 1        /* mirror_material.hpp:20-56        color_a = reflectance, roughness     */
 #define FCGPU_MATERIAL_GLASS 2         /* glass_material.hpp:19-41         color_a = reflectance, color_b = transmittance, roughness */

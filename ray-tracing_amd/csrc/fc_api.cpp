@@ -1,0 +1,594 @@
+// fc_api.cpp -- implementation of the C-ABI of include/fcgpu.h: context, scene upload, pass
+// scheduling (the host side of the wavefront loop), film read-out.
+//
+// Host-side counterpart of renderer::run / worker_thread / export_image
+// (src/renderer/renderer.hpp:65-113, 154-179, 115-141): instead of threads pulling pixels it
+// cuts a pass into batches of at most `max_paths_in_flight` paths and, per batch, enqueues
+// generate -> { extend -> shade<lobe>... -> shadow } x max_path_length -> accumulate on one HIP
+// stream. Nothing here computes radiance on the CPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fcgpu.h"
+#include "fc_host.h"
+#include "fc_kernels.h"
+
+using namespace fcg;
+
+namespace
+{
+    thread_local std::string g_create_error;
+
+    constexpr uint32_t DEFAULT_PATHS_IN_FLIGHT = 1u << 21;
+}
+
+struct fcgpu_ctx
+{
+    int device{};
+    hipStream_t stream{};
+    std::string err;
+    fcgpu_options opt{};
+    uint64_t seed{};
+    bool has_scene{};
+    FlatScene flat;  // host copy (typed arrays are small; nodes/tris are kept for introspection)
+    std::vector<void*> scene_allocs;
+    std::vector<void*> queue_allocs;
+    SceneDev<float> s32{};
+    SceneDev<double> s64{};
+    Wavefront<float> q32{};
+    Wavefront<double> q64{};
+    int queue_precision{-1};
+    uint32_t queue_capacity{};
+    double* film{};
+    uint64_t film_elems{};
+    QueueCounters* counters{};
+    unsigned long long* stats{};
+    uint64_t samples{};
+    uint64_t launches{};
+    int grid{};
+};
+
+namespace
+{
+    int fail(fcgpu_ctx* c, int code, const std::string& msg)
+    {
+        if(c) c->err = msg;
+        return code;
+    }
+
+    int hip_fail(fcgpu_ctx* c, hipError_t e, const char* what)
+    {
+        return fail(c, FCGPU_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+
+#define HIP_TRY(c, call)                                 \
+    do                                                   \
+    {                                                    \
+        hipError_t e_ = (call);                          \
+        if(e_ != hipSuccess) return hip_fail(c, e_, #call); \
+    } while(0)
+
+    template<typename T> int upload(fcgpu_ctx* c, std::vector<void*>& pool, const std::vector<T>& v, const T** out)
+    {
+        void* p = nullptr;
+        size_t bytes = std::max<size_t>(sizeof(T) * v.size(), 16);
+        HIP_TRY(c, hipMalloc(&p, bytes));
+        pool.push_back(p);
+        if(!v.empty()) HIP_TRY(c, hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+        *out = static_cast<const T*>(p);
+        return FCGPU_OK;
+    }
+
+    void free_pool(std::vector<void*>& pool)
+    {
+        for(void* p : pool) (void)hipFree(p);
+        pool.clear();
+    }
+
+    template<typename R> int fill_scene(fcgpu_ctx* c, SceneDev<R>& S, const FlatTyped<R>& T)
+    {
+        int rc;
+        if((rc = upload(c, c->scene_allocs, T.xprims, &S.xprims))) return rc;
+        if((rc = upload(c, c->scene_allocs, T.lobes, &S.lobes))) return rc;
+        if((rc = upload(c, c->scene_allocs, T.media, &S.media))) return rc;
+        if((rc = upload(c, c->scene_allocs, T.lights, &S.lights))) return rc;
+        S.camera = T.camera;
+        for(int k = 0; k < 3; ++k) S.env[k] = T.env[k];
+        S.light_count = c->flat.light_count;
+        S.env_kind = c->flat.env_kind;
+        return FCGPU_OK;
+    }
+
+    double effective_epsilon(const fcgpu_ctx* c)
+    {
+        if(c->opt.epsilon > 0.0) return c->opt.epsilon;
+        return c->opt.precision == FCGPU_PRECISION_F64 ? 1e-6 : 1e-4;
+    }
+
+    template<typename R> int alloc_wavefront(fcgpu_ctx* c, Wavefront<R>& Q, uint32_t cap)
+    {
+        auto col = [&](Vec4<R>** out) -> int
+        {
+            void* p = nullptr;
+            HIP_TRY(c, hipMalloc(&p, sizeof(Vec4<R>) * static_cast<size_t>(cap)));
+            c->queue_allocs.push_back(p);
+            *out = static_cast<Vec4<R>*>(p);
+            return FCGPU_OK;
+        };
+        int rc;
+        if((rc = col(&Q.ray_c0)) || (rc = col(&Q.ray_c1))) return rc;
+        if((rc = col(&Q.sh_c0)) || (rc = col(&Q.sh_c1)) || (rc = col(&Q.sh_c2))) return rc;
+        // one hit queue per key that can occur in this scene (lobe types present, last vertex, miss)
+        for(int k = 0; k < Q_COUNT; ++k)
+        {
+            bool needed = k == Q_FINAL || (k == Q_MISS && c->flat.env_kind != FCGPU_ENV_NONE) || (k < L_COUNT && (c->flat.lobe_mask >> k & 1u));
+            Q.hit_c0[k] = nullptr;
+            Q.hit_c1[k] = nullptr;
+            if(!needed) continue;
+            if((rc = col(&Q.hit_c0[k])) || (rc = col(&Q.hit_c1[k]))) return rc;
+        }
+        void* p = nullptr;
+        HIP_TRY(c, hipMalloc(&p, sizeof(PathState<R>) * static_cast<size_t>(cap)));
+        c->queue_allocs.push_back(p);
+        Q.state = static_cast<PathState<R>*>(p);
+        Q.counters = c->counters;
+        Q.stats = c->stats;
+        Q.capacity = cap;
+        return FCGPU_OK;
+    }
+
+    int ensure_queues(fcgpu_ctx* c)
+    {
+        uint32_t cap = c->opt.max_paths_in_flight ? c->opt.max_paths_in_flight : DEFAULT_PATHS_IN_FLIGHT;
+        if(c->queue_precision == c->opt.precision && c->queue_capacity == cap) return FCGPU_OK;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        free_pool(c->queue_allocs);
+        c->queue_precision = -1;
+        int rc = c->opt.precision == FCGPU_PRECISION_F64 ? alloc_wavefront(c, c->q64, cap) : alloc_wavefront(c, c->q32, cap);
+        if(rc)
+        {
+            free_pool(c->queue_allocs);
+            return rc;
+        }
+        c->queue_precision = c->opt.precision;
+        c->queue_capacity = cap;
+        return FCGPU_OK;
+    }
+
+    template<typename R>
+    int run_batches(fcgpu_ctx* c, SceneDev<R> S, const Wavefront<R>& Q, const fcgpu_tile& tile, uint32_t sample_begin,
+                    uint32_t sample_count, int integrator, int max_len, int visible_env)
+    {
+        S.epsilon = static_cast<R>(effective_epsilon(c));
+        LaunchCfg L{c->stream, c->grid};
+        const uint64_t P = static_cast<uint64_t>(tile.w) * static_cast<uint64_t>(tile.h);
+        const uint64_t cap = Q.capacity;
+
+        Batch B{};
+        B.x0 = tile.x0;
+        B.y0 = tile.y0;
+        B.tw = tile.w;
+        B.seed = c->seed;
+        B.max_len = max_len;
+        B.integrator = integrator;
+        B.visible_env = visible_env;
+        B.W = c->flat.width;
+        B.film = c->film;
+
+        auto run_one = [&](uint32_t pix0, uint32_t npix, uint32_t s0, uint32_t nsamp)
+        {
+            B.pix0 = pix0;
+            B.npix = npix;
+            B.s0 = s0;
+            B.nsamp = nsamp;
+            B.parity = 0;
+            B.h = 1;
+            launch_reset_counters(L, c->counters, 0);
+            launch_generate(L, S, Q, B);
+            c->launches += 2;
+            for(int h = 1; h <= max_len; ++h)
+            {
+                B.h = h;
+                if(h > 1)
+                {
+                    launch_reset_counters(L, c->counters, B.parity);
+                    c->launches += 1;
+                }
+                launch_extend(L, S, Q, B);
+                c->launches += 1;
+                if(h < max_len)
+                {
+                    for(int k = 0; k < L_COUNT; ++k)
+                    {
+                        if(c->flat.lobe_mask >> k & 1u)
+                        {
+                            launch_shade(L, S, Q, B, k);
+                            c->launches += 1;
+                        }
+                    }
+                }
+                else
+                {
+                    launch_shade(L, S, Q, B, Q_FINAL);
+                    c->launches += 1;
+                }
+                if(c->flat.env_kind != FCGPU_ENV_NONE)
+                {
+                    launch_shade(L, S, Q, B, Q_MISS);
+                    c->launches += 1;
+                }
+                if(h < max_len && integrator == FCGPU_INTEGRATOR_MIS)
+                {
+                    launch_shadow(L, S, Q, B);
+                    c->launches += 1;
+                }
+                B.parity ^= 1;
+            }
+            launch_accumulate(L, S, Q, B);
+            c->launches += 1;
+        };
+
+        if(P >= cap)
+        {
+            // pixel ranges of one sample
+            for(uint32_t s = 0; s < sample_count; ++s)
+                for(uint64_t p0 = 0; p0 < P; p0 += cap)
+                    run_one(static_cast<uint32_t>(p0), static_cast<uint32_t>(std::min<uint64_t>(cap, P - p0)), sample_begin + s, 1);
+        }
+        else
+        {
+            // whole samples over all pixels of the tile
+            uint32_t per = static_cast<uint32_t>(cap / P);
+            for(uint32_t s = 0; s < sample_count; s += per)
+                run_one(0, static_cast<uint32_t>(P), sample_begin + s, std::min(per, sample_count - s));
+        }
+        hipError_t e = hipGetLastError();
+        if(e != hipSuccess) return hip_fail(c, e, "kernel launch");
+        c->samples += P * sample_count;
+        return FCGPU_OK;
+    }
+
+    template<typename R>
+    int run_trace(fcgpu_ctx* c, SceneDev<R> S, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits, uint8_t* occ)
+    {
+        S.epsilon = static_cast<R>(effective_epsilon(c));
+        LaunchCfg L{c->stream, c->grid};
+        launch_trace(L, S, n, rays, hits, occ, c->stats);
+        c->launches += 1;
+        hipError_t e = hipGetLastError();
+        if(e != hipSuccess) return hip_fail(c, e, "trace launch");
+        return FCGPU_OK;
+    }
+
+    int trace_device(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits, uint8_t* occ)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+        if(n == 0) return FCGPU_OK;
+        if(!rays || (!hits && !occ)) return fail(c, FCGPU_E_INVALID, "null buffer");
+        HIP_TRY(c, hipSetDevice(c->device));
+        return c->opt.precision == FCGPU_PRECISION_F64 ? run_trace(c, c->s64, n, rays, hits, occ) : run_trace(c, c->s32, n, rays, hits, occ);
+    }
+
+    int trace_host(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits, uint8_t* occ)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+        if(n == 0) return FCGPU_OK;
+        if(!rays || (!hits && !occ)) return fail(c, FCGPU_E_INVALID, "null buffer");
+        HIP_TRY(c, hipSetDevice(c->device));
+        fcgpu_ray* d_rays = nullptr;
+        void* d_out = nullptr;
+        size_t out_bytes = hits ? sizeof(fcgpu_hit) * n : n;
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_rays), sizeof(fcgpu_ray) * n));
+        hipError_t e = hipMalloc(&d_out, out_bytes);
+        if(e != hipSuccess)
+        {
+            (void)hipFree(d_rays);
+            return hip_fail(c, e, "hipMalloc");
+        }
+        int rc = FCGPU_OK;
+        e = hipMemcpyAsync(d_rays, rays, sizeof(fcgpu_ray) * n, hipMemcpyHostToDevice, c->stream);
+        if(e == hipSuccess) rc = trace_device(c, n, d_rays, hits ? static_cast<fcgpu_hit*>(d_out) : nullptr, hits ? nullptr : static_cast<uint8_t*>(d_out));
+        if(e == hipSuccess && rc == FCGPU_OK) e = hipMemcpyAsync(hits ? static_cast<void*>(hits) : static_cast<void*>(occ), d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+        if(e == hipSuccess && rc == FCGPU_OK) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_rays);
+        (void)hipFree(d_out);
+        if(rc != FCGPU_OK) return rc;
+        if(e != hipSuccess) return hip_fail(c, e, "trace copy");
+        return FCGPU_OK;
+    }
+}
+
+extern "C"
+{
+    int fcgpu_version(void) { return 1000; }
+
+    int fcgpu_create(int device, fcgpu_ctx** out)
+    {
+        if(!out)
+        {
+            g_create_error = "null output pointer";
+            return FCGPU_E_INVALID;
+        }
+        *out = nullptr;
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if(e != hipSuccess || device < 0 || device >= count)
+        {
+            g_create_error = e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e) : "no such HIP device";
+            return e != hipSuccess ? FCGPU_E_HIP : FCGPU_E_INVALID;
+        }
+        fcgpu_ctx* c = new(std::nothrow) fcgpu_ctx{};
+        if(!c)
+        {
+            g_create_error = "out of host memory";
+            return FCGPU_E_NOMEM;
+        }
+        c->device = device;
+        c->opt.precision = FCGPU_PRECISION_F32;
+        c->opt.sort_materials = 1;
+        auto bail = [&](hipError_t err, const char* what)
+        {
+            g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+            if(c->counters) (void)hipFree(c->counters);
+            if(c->stats) (void)hipFree(c->stats);
+            if(c->stream) (void)hipStreamDestroy(c->stream);
+            delete c;
+            return FCGPU_E_HIP;
+        };
+        if((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+        if((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+        if((e = hipMalloc(reinterpret_cast<void**>(&c->counters), sizeof(QueueCounters))) != hipSuccess) return bail(e, "hipMalloc");
+        if((e = hipMalloc(reinterpret_cast<void**>(&c->stats), sizeof(unsigned long long) * ST_COUNT)) != hipSuccess) return bail(e, "hipMalloc");
+        if((e = hipMemset(c->counters, 0, sizeof(QueueCounters))) != hipSuccess) return bail(e, "hipMemset");
+        if((e = hipMemset(c->stats, 0, sizeof(unsigned long long) * ST_COUNT)) != hipSuccess) return bail(e, "hipMemset");
+        hipDeviceProp_t prop{};
+        if((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+        c->grid = std::max(1, prop.multiProcessorCount) * 8;
+        *out = c;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_destroy(fcgpu_ctx* c)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        free_pool(c->scene_allocs);
+        free_pool(c->queue_allocs);
+        if(c->film) (void)hipFree(c->film);
+        (void)hipFree(c->counters);
+        (void)hipFree(c->stats);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return FCGPU_OK;
+    }
+
+    const char* fcgpu_last_error(const fcgpu_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+    int fcgpu_set_options(fcgpu_ctx* c, const fcgpu_options* opt)
+    {
+        if(!c || !opt) return fail(c, FCGPU_E_INVALID, "null argument");
+        if(opt->precision != FCGPU_PRECISION_F32 && opt->precision != FCGPU_PRECISION_F64) return fail(c, FCGPU_E_INVALID, "unknown precision");
+        if(opt->max_paths_in_flight != 0 && opt->max_paths_in_flight < 256) return fail(c, FCGPU_E_INVALID, "max_paths_in_flight < 256");
+        c->opt = *opt;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_set_sampler(fcgpu_ctx* c, uint64_t seed)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        c->seed = seed;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_upload_scene(fcgpu_ctx* c, const fcgpu_scene_desc* d)
+    {
+        if(!c || !d) return fail(c, FCGPU_E_INVALID, "null argument");
+        HIP_TRY(c, hipSetDevice(c->device));
+        FlatScene flat;
+        std::string err;
+        int rc = flatten_scene(*d, flat, err);
+        if(rc != FCGPU_OK) return fail(c, rc, err);
+
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        free_pool(c->scene_allocs);
+        free_pool(c->queue_allocs);  // hit queues depend on the lobe types of the scene
+        c->queue_precision = -1;
+        c->has_scene = false;
+        c->flat = std::move(flat);
+
+        SceneDev<float> a{};
+        if((rc = upload(c, c->scene_allocs, c->flat.nodes, &a.nodes))) return rc;
+        if((rc = upload(c, c->scene_allocs, c->flat.leaf_prims, &a.leaf_prims))) return rc;
+        if((rc = upload(c, c->scene_allocs, c->flat.tris, &a.tris))) return rc;
+        if((rc = upload(c, c->scene_allocs, c->flat.tri_attrs, &a.tri_attrs))) return rc;
+        if((rc = upload(c, c->scene_allocs, c->flat.prim_info, &a.prim_info))) return rc;
+        if((rc = upload(c, c->scene_allocs, c->flat.entities, &a.entities))) return rc;
+        if((rc = upload(c, c->scene_allocs, c->flat.materials, &a.materials))) return rc;
+        if((rc = upload(c, c->scene_allocs, c->flat.light_cdf, &a.light_cdf))) return rc;
+        SceneDev<double> b{};
+        b.nodes = a.nodes;
+        b.leaf_prims = a.leaf_prims;
+        b.tris = a.tris;
+        b.tri_attrs = a.tri_attrs;
+        b.prim_info = a.prim_info;
+        b.entities = a.entities;
+        b.materials = a.materials;
+        b.light_cdf = a.light_cdf;
+        if((rc = fill_scene(c, a, c->flat.f32))) return rc;
+        if((rc = fill_scene(c, b, c->flat.f64))) return rc;
+        c->s32 = a;
+        c->s64 = b;
+
+        if(c->film) (void)hipFree(c->film);
+        c->film = nullptr;
+        c->film_elems = 3ull * static_cast<uint64_t>(c->flat.width) * static_cast<uint64_t>(c->flat.height);
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->film), sizeof(double) * c->film_elems));
+        HIP_TRY(c, hipMemset(c->film, 0, sizeof(double) * c->film_elems));
+        c->samples = 0;
+        c->has_scene = true;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_render_pass(fcgpu_ctx* c, const fcgpu_tile* tile, uint32_t sample_begin, uint32_t sample_count, int integrator,
+                          int max_path_length, int visible_infinity_area_light)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+        fcgpu_tile full{0, 0, c->flat.width, c->flat.height};
+        if(!tile) tile = &full;
+        if(tile->w <= 0 || tile->h <= 0 || tile->x0 < 0 || tile->y0 < 0 || tile->x0 + tile->w > c->flat.width || tile->y0 + tile->h > c->flat.height)
+            return fail(c, FCGPU_E_INVALID, "tile outside the film");
+        if(integrator != FCGPU_INTEGRATOR_BSDF && integrator != FCGPU_INTEGRATOR_MIS) return fail(c, FCGPU_E_INVALID, "unknown integrator");
+        if(max_path_length < 1 || max_path_length > 1000) return fail(c, FCGPU_E_INVALID, "max_path_length out of range");
+        if(static_cast<uint64_t>(sample_begin) + sample_count > (1u << 24)) return fail(c, FCGPU_E_LIMIT, "sample index >= 2^24");
+        if(sample_count == 0) return FCGPU_OK;
+        HIP_TRY(c, hipSetDevice(c->device));
+        int rc = ensure_queues(c);
+        if(rc) return rc;
+        if(c->opt.precision == FCGPU_PRECISION_F64)
+            return run_batches(c, c->s64, c->q64, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
+        return run_batches(c, c->s32, c->q32, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
+    }
+
+    int fcgpu_trace_closest(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits)
+    {
+        if(c && !hits && n) return fail(c, FCGPU_E_INVALID, "null hits");
+        return trace_host(c, n, rays, hits, nullptr);
+    }
+    int fcgpu_trace_any(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays, uint8_t* occluded)
+    {
+        if(c && !occluded && n) return fail(c, FCGPU_E_INVALID, "null output");
+        return trace_host(c, n, rays, nullptr, occluded);
+    }
+    int fcgpu_trace_closest_device(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays_dev, fcgpu_hit* hits_dev)
+    {
+        if(c && !hits_dev && n) return fail(c, FCGPU_E_INVALID, "null hits");
+        return trace_device(c, n, rays_dev, hits_dev, nullptr);
+    }
+    int fcgpu_trace_any_device(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays_dev, uint8_t* occluded_dev)
+    {
+        if(c && !occluded_dev && n) return fail(c, FCGPU_E_INVALID, "null output");
+        return trace_device(c, n, rays_dev, nullptr, occluded_dev);
+    }
+
+    int fcgpu_clear_film(fcgpu_ctx* c)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipMemsetAsync(c->film, 0, sizeof(double) * c->film_elems, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->samples = 0;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_read_film(fcgpu_ctx* c, double* rgb_sum, uint64_t* sample_count)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if(rgb_sum)
+        {
+            HIP_TRY(c, hipMemcpy(rgb_sum, c->film, sizeof(double) * c->film_elems, hipMemcpyDeviceToHost));
+            // beta0 = W*H (perspective_camera.hpp:64-68) is applied here instead of per sample
+            const double scale = static_cast<double>(c->flat.width) * static_cast<double>(c->flat.height);
+            for(uint64_t i = 0; i < c->film_elems; ++i) rgb_sum[i] *= scale;
+        }
+        if(sample_count) *sample_count = c->samples;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_film_device_ptr(fcgpu_ctx* c, void** rgb_dev, uint64_t* bytes)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+        if(rgb_dev) *rgb_dev = c->film;
+        if(bytes) *bytes = sizeof(double) * c->film_elems;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_add_sample_count(fcgpu_ctx* c, int64_t delta)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        c->samples = static_cast<uint64_t>(static_cast<int64_t>(c->samples) + delta);
+        return FCGPU_OK;
+    }
+
+    int fcgpu_get_counters(fcgpu_ctx* c, fcgpu_counters* out)
+    {
+        if(!c || !out) return fail(c, FCGPU_E_INVALID, "null argument");
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        unsigned long long st[ST_COUNT];
+        HIP_TRY(c, hipMemcpy(st, c->stats, sizeof(st), hipMemcpyDeviceToHost));
+        std::memset(out, 0, sizeof(*out));
+        out->samples = c->samples;
+        out->closest_rays = st[ST_CLOSEST];
+        out->shadow_rays = st[ST_SHADOW];
+        out->shadow_occluded = st[ST_OCCLUDED];
+        out->nan_samples = st[ST_NAN];
+        out->stack_overflows = st[ST_STACK_OVERFLOW];
+        out->bvh_nodes = c->flat.nodes.size();
+        out->primitives = c->flat.prim_info.size();
+        out->kernel_launches = c->launches;
+        out->reserved[0] = st[ST_MEDIUM_OVERFLOW];
+        out->reserved[1] = c->flat.max_stack;
+        out->reserved[2] = c->flat.binary_nodes;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_reset_counters(fcgpu_ctx* c)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
+        c->launches = 0;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_sync(fcgpu_ctx* c)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return FCGPU_OK;
+    }
+
+    int fcgpu_stream(fcgpu_ctx* c, void** stream)
+    {
+        if(!c || !stream) return fail(c, FCGPU_E_INVALID, "null argument");
+        *stream = c->stream;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_export_image(fcgpu_ctx* c, const char* name)
+    {
+        if(!c || !name) return fail(c, FCGPU_E_INVALID, "null argument");
+        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+        std::vector<double> sum(c->film_elems);
+        uint64_t count = 0;
+        int rc = fcgpu_read_film(c, sum.data(), &count);
+        if(rc) return rc;
+        std::string path = std::string(name) + ".raw";
+        FILE* f = std::fopen(path.c_str(), "wb");
+        if(!f) return fail(c, FCGPU_E_INVALID, "cannot open " + path);
+        std::vector<float> row(3 * static_cast<size_t>(c->flat.width));
+        for(int y = 0; y < c->flat.height; ++y)
+        {
+            for(size_t i = 0; i < row.size(); ++i) row[i] = static_cast<float>(sum[static_cast<size_t>(y) * row.size() + i] / static_cast<double>(count));
+            std::fwrite(row.data(), sizeof(float), row.size(), f);
+        }
+        std::fclose(f);
+        return FCGPU_OK;
+    }
+}

@@ -1,0 +1,445 @@
+// fc_bsdf.h -- device-side BSDF evaluators (generic over R).
+//
+// Restates, for the GPU, the lobe classes of src/bsdfs/ and the two adapter layers above them:
+//   lobe (one-sided, written for the adjoint direction)      src/bsdfs/*.hpp
+//   bxdf_adapter<T> (side flip, eta swap, eta^2 scaling)      src/core/bxdf.hpp:57-127
+//   bsdf (shading frame, ng/ns consistency, lobe factor)      src/core/bsdf.hpp:62-100,131-141
+// Local shading space is y-up: local = (w.t, w.ns, w.b) (bsdf.hpp:156-172).
+// normal_mapping<T> is taken on its `skip_` path (normal_mapping.hpp:34-35,745-750), which is
+// the only path reachable without a normal-map texture.
+#pragma once
+#include "fc_types.h"
+
+namespace fcg
+{
+    // ---------------------------------------------------------------- common.hpp
+    template<typename R> FC_HD R fr_dielectric(R cos_i, R eta_i, R eta_t)  // common.hpp:8-20
+    {
+        cos_i = clampr(cos_i, R(-1), R(1));
+        R sin_i = r_sqrt(r_max(R(0), R(1) - cos_i * cos_i));
+        R sin_t = eta_i / eta_t * sin_i;
+        if(sin_t >= R(1)) return R(1);
+        R cos_t = r_sqrt(r_max(R(0), R(1) - sin_t * sin_t));
+        R r_parl = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+        R r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+        return (r_parl * r_parl + r_perp * r_perp) / R(2);
+    }
+
+    template<typename R> FC_HD vec3<R> reflect(vec3<R> w, vec3<R> n)  // common.hpp:22-25
+    {
+        return -w + (R(2) * dot(w, n)) * n;
+    }
+
+    template<typename R> FC_HD bool refract(vec3<R> i, vec3<R> m, R eta, vec3<R>& o)  // common.hpp:27-39
+    {
+        R cos_i = dot(i, m);
+        R sin2_i = r_max(R(0), R(1) - cos_i * cos_i);
+        R sin2_t = eta * eta * sin2_i;
+        if(sin2_t >= R(1)) return false;
+        R cos_t = r_sqrt(R(1) - sin2_t);
+        o = eta * (-i) + (eta * cos_i - cos_t) * m;
+        return true;
+    }
+
+    // ---------------------------------------------------------------- sampling.hpp
+    template<typename R> FC_HD void sample_disk_concentric(R ux, R uy, R& dx, R& dy)  // sampling.hpp:6-29
+    {
+        R ox = ux * R(2) - R(1), oy = uy * R(2) - R(1);
+        if(ox == R(0) && oy == R(0))
+        {
+            dx = R(0);
+            dy = R(0);
+            return;
+        }
+        R theta, r;
+        if(r_abs(ox) > r_abs(oy))
+        {
+            r = ox;
+            theta = consts<R>::pi * oy / (R(4) * ox);
+        }
+        else
+        {
+            r = oy;
+            theta = consts<R>::pi / R(2) - consts<R>::pi * ox / (R(4) * oy);
+        }
+        dx = r * r_cos(theta);
+        dy = r * r_sin(theta);
+    }
+
+    template<typename R> FC_HD vec3<R> sample_hemisphere_cosine(R ux, R uy)  // sampling.hpp:31-35
+    {
+        R dx, dy;
+        sample_disk_concentric(ux, uy, dx, dy);
+        return {dx, r_sqrt(r_max(R(0), R(1) - dx * dx - dy * dy)), dy};
+    }
+
+    template<typename R> FC_HD vec3<R> sample_sphere_uniform(R ux, R uy)  // sampling.hpp:49-55
+    {
+        R z = R(1) - R(2) * ux;
+        R r = r_sqrt(r_max(R(0), R(1) - z * z));
+        R phi = R(2) * consts<R>::pi * uy;
+        return {r * r_cos(phi), z, r * r_sin(phi)};
+    }
+
+    // ---------------------------------------------------------------- microfacet.hpp (Smith GGX)
+    template<typename R>
+    struct Ggx
+    {
+        R ax, ay;
+
+        FC_HD vec3<R> sample(vec3<R> i, R ux, R uy) const  // microfacet.hpp:28-44
+        {
+            vec3<R> ih = normalize(vec3<R>{ax * i.x, i.y, ay * i.z});
+            R lensq = ih.x * ih.x + ih.z * ih.z;
+            vec3<R> T1 = lensq > R(0) ? vec3<R>{-ih.z, R(0), ih.x} / r_sqrt(lensq) : vec3<R>{R(1), R(0), R(0)};
+            vec3<R> T2 = cross(T1, ih);
+            R r = r_sqrt(ux);
+            R phi = R(2) * consts<R>::pi * uy;
+            R t1 = r * r_cos(phi);
+            R t2 = r * r_sin(phi);
+            R s = R(0.5) * (R(1) + ih.y);
+            t2 = (R(1) - s) * r_sqrt(R(1) - t1 * t1) + s * t2;
+            vec3<R> Nh = t1 * T1 + t2 * T2 + r_sqrt(r_max(R(0), R(1) - t1 * t1 - t2 * t2)) * ih;
+            return normalize(vec3<R>{ax * Nh.x, r_max(R(0), Nh.y), ay * Nh.z});
+        }
+        FC_HD R D(vec3<R> m) const  // :51-55
+        {
+            R x = m.x * m.x / (ax * ax) + m.y * m.y + m.z * m.z / (ay * ay);
+            return R(1) / (consts<R>::pi * ax * ay * x * x);
+        }
+        FC_HD R lambda(vec3<R> i) const  // :70-74
+        {
+            R x = (ax * ax * i.x * i.x + ay * ay * i.z * i.z) / (i.y * i.y);
+            return (R(-1) + r_sqrt(R(1) + x)) / R(2);
+        }
+        FC_HD R G1(vec3<R> i) const { return R(1) / (R(1) + lambda(i)); }                  // :57-60
+        FC_HD R G2(vec3<R> i, vec3<R> o) const { return R(1) / (R(1) + lambda(i) + lambda(o)); }  // :62-65
+        FC_HD R pdf(vec3<R> i, vec3<R> m) const { return G1(i) * r_max(R(0), dot(i, m)) * D(m) / i.y; }  // :46-49
+    };
+
+    template<typename R> FC_HD vec3<R> rgb(const R* c) { return {c[0], c[1], c[2]}; }
+
+    template<typename R> FC_HD R lobe_fresnel(const LobeRec<R>& L, R cos_i, R eta_a)  // microfacet_reflection.hpp:18-35
+    {
+        return L.fresnel ? fr_dielectric(cos_i, eta_a, L.ior) : R(1);
+    }
+
+    // half vector of the transmission lobes, oriented as microfacet_glass.hpp:38-51; false = rejected
+    template<typename R> FC_HD bool refraction_half(vec3<R> i, vec3<R> o, R eta_a, R eta_b, vec3<R>& h, R& i_dot_h, R& o_dot_h)
+    {
+        h = normalize(-(eta_a * i + eta_b * o));
+        if(eta_a <= eta_b)
+        {
+            if(h.y <= R(0)) return false;
+        }
+        else
+        {
+            if(h.y >= R(0)) return false;
+            h = -h;
+        }
+        i_dot_h = dot(i, h);
+        o_dot_h = dot(o, h);
+        return !(i_dot_h <= R(0) || o_dot_h >= R(0));
+    }
+
+    // ---------------------------------------------------------------- one-sided lobes
+    // T::evaluate(i, o, eta_a, eta_b)
+    template<int TYPE, typename R>
+    FC_HD vec3<R> lobe_evaluate(const LobeRec<R>& L, vec3<R> i, vec3<R> o, R eta_a, R eta_b)
+    {
+        const vec3<R> zero{R(0), R(0), R(0)};
+        if constexpr(TYPE == L_LAMBERT)  // lambertian_reflection.hpp:20-24
+        {
+            if(i.y <= R(0) || o.y <= R(0)) return zero;
+            return rgb(L.color) * consts<R>::inv_pi;
+        }
+        else if constexpr(TYPE == L_GGX_REFL)  // microfacet_reflection.hpp:49-59
+        {
+            if(o.y <= R(0)) return zero;
+            Ggx<R> g{L.alpha[0], L.alpha[1]};
+            vec3<R> h = normalize(i + o);
+            R G = g.G2(i, o);
+            R D = g.D(h);
+            R F = lobe_fresnel(L, dot(i, h), eta_a);
+            return rgb(L.color) * (F * (G * D / (R(4) * i.y * o.y)));
+        }
+        else if constexpr(TYPE == L_GGX_GLASS)  // microfacet_glass.hpp:22-61
+        {
+            if(i.y == R(0) || o.y == R(0)) return zero;
+            Ggx<R> g{L.alpha[0], L.alpha[1]};
+            if(o.y > R(0))
+            {
+                vec3<R> h = normalize(i + o);
+                R G = g.G2(i, o);
+                R D = g.D(h);
+                R F = fr_dielectric(dot(i, h), eta_a, eta_b);
+                return rgb(L.color) * (G * D * F / (R(4) * i.y * o.y));
+            }
+            vec3<R> h;
+            R idh, odh;
+            if(!refraction_half(i, o, eta_a, eta_b, h, idh, odh)) return zero;
+            R eta = eta_a / eta_b;
+            R J = -odh / sqr(eta * idh + odh);
+            R G = g.G2(i, o);
+            R D = g.D(h);
+            R F = fr_dielectric(idh, eta_a, eta_b);
+            return rgb(L.color2) * (idh * G * D * J * (R(1) - F) / (i.y * -o.y));
+        }
+        else if constexpr(TYPE == L_GGX_TRANS)  // microfacet_transmission.hpp:21-46
+        {
+            if(o.y >= R(0)) return zero;
+            Ggx<R> g{L.alpha[0], L.alpha[1]};
+            vec3<R> h;
+            R idh, odh;
+            if(!refraction_half(i, o, eta_a, eta_b, h, idh, odh)) return zero;
+            R eta = eta_a / eta_b;
+            R J = -odh / sqr(eta * idh + odh);
+            return rgb(L.color) * (idh * g.G2(i, o) * g.D(h) * J / (i.y * -o.y));
+        }
+        else  // delta lobes: specular_*.hpp evaluate == 0
+        {
+            return zero;
+        }
+    }
+
+    // T::pdf(i, o, eta_a, eta_b)
+    template<int TYPE, typename R>
+    FC_HD R lobe_pdf(const LobeRec<R>& L, vec3<R> i, vec3<R> o, R eta_a, R eta_b)
+    {
+        if constexpr(TYPE == L_LAMBERT)  // lambertian_reflection.hpp:42-46
+        {
+            if(i.y <= R(0) || o.y <= R(0)) return R(0);
+            return o.y * consts<R>::inv_pi;
+        }
+        else if constexpr(TYPE == L_GGX_REFL)  // microfacet_reflection.hpp:88-95
+        {
+            if(o.y <= R(0)) return R(0);
+            Ggx<R> g{L.alpha[0], L.alpha[1]};
+            vec3<R> h = normalize(i + o);
+            return g.pdf(i, h) * (R(1) / (R(4) * dot(i, h)));
+        }
+        else if constexpr(TYPE == L_GGX_GLASS)  // microfacet_glass.hpp:123-160
+        {
+            if(i.y == R(0) || o.y == R(0)) return R(0);
+            Ggx<R> g{L.alpha[0], L.alpha[1]};
+            if(o.y > R(0))
+            {
+                vec3<R> h = normalize(i + o);
+                R idh = dot(i, h);
+                R F = fr_dielectric(idh, eta_a, eta_b);
+                return g.pdf(i, h) * (R(1) / (R(4) * idh)) * F;
+            }
+            vec3<R> h;
+            R idh, odh;
+            if(!refraction_half(i, o, eta_a, eta_b, h, idh, odh)) return R(0);
+            R eta = eta_a / eta_b;
+            R F = fr_dielectric(idh, eta_a, eta_b);
+            R J = -odh / sqr(eta * idh + odh);
+            return g.pdf(i, h) * J * (R(1) - F);
+        }
+        else if constexpr(TYPE == L_GGX_TRANS)  // microfacet_transmission.hpp:85-108
+        {
+            if(o.y >= R(0)) return R(0);
+            Ggx<R> g{L.alpha[0], L.alpha[1]};
+            vec3<R> h;
+            R idh, odh;
+            if(!refraction_half(i, o, eta_a, eta_b, h, idh, odh)) return R(0);
+            R eta = eta_a / eta_b;
+            R J = -odh / sqr(eta * idh + odh);
+            return g.pdf(i, h) * J;
+        }
+        else
+        {
+            return R(0);
+        }
+    }
+
+    // T::sample(i, eta_a, eta_b, u1, u2, &o, &value, &pdf_o)
+    template<int TYPE, typename R>
+    FC_HD bool lobe_sample(const LobeRec<R>& L, vec3<R> i, R eta_a, R eta_b, R u1x, R u1y, R u2x, R u2y,
+                           vec3<R>& o, vec3<R>& value, R& pdf_o)
+    {
+        (void)u2y;
+        if constexpr(TYPE == L_LAMBERT)  // lambertian_reflection.hpp:26-40
+        {
+            if(i.y <= R(0)) return false;
+            o = sample_hemisphere_cosine(u1x, u1y);
+            if(o.y == R(0)) return false;
+            value = rgb(L.color) * consts<R>::inv_pi;
+            pdf_o = o.y * consts<R>::inv_pi;
+            return true;
+        }
+        else if constexpr(TYPE == L_GGX_REFL)  // microfacet_reflection.hpp:61-86
+        {
+            if(i.y == R(0)) return false;
+            Ggx<R> g{L.alpha[0], L.alpha[1]};
+            vec3<R> h = g.sample(i, u1x, u1y);
+            R idh = dot(i, h);
+            if(idh <= R(0)) return false;
+            o = reflect(i, h);
+            if(o.y <= R(0)) return false;
+            R G = g.G2(i, o);
+            R D = g.D(h);
+            R F = lobe_fresnel(L, idh, eta_a);
+            value = rgb(L.color) * (F * (G * D / (R(4) * i.y * o.y)));
+            pdf_o = g.pdf(i, h) * (R(1) / (R(4) * idh));
+            return true;
+        }
+        else if constexpr(TYPE == L_SPEC_REFL)  // specular_reflection.hpp:25-40
+        {
+            if(i.y == R(0)) return false;
+            R F = lobe_fresnel(L, i.y, eta_a);
+            o = vec3<R>{-i.x, i.y, -i.z};
+            value = rgb(L.color) * F / o.y;
+            pdf_o = R(1);
+            return true;
+        }
+        else if constexpr(TYPE == L_GGX_GLASS)  // microfacet_glass.hpp:63-121
+        {
+            if(i.y == R(0)) return false;
+            Ggx<R> g{L.alpha[0], L.alpha[1]};
+            vec3<R> h = g.sample(i, u1x, u1y);
+            R idh = dot(i, h);
+            if(idh <= R(0)) return false;
+            R F = fr_dielectric(idh, eta_a, eta_b);
+            if(u2x < F)
+            {
+                o = reflect(i, h);
+                if(o.y <= R(0)) return false;
+                R G = g.G2(i, o);
+                R D = g.D(h);
+                value = rgb(L.color) * (G * D * F / (R(4) * i.y * o.y));
+                pdf_o = g.pdf(i, h) * (R(1) / (R(4) * idh)) * F;
+                return true;
+            }
+            R eta = eta_a / eta_b;
+            if(!refract(i, h, eta, o)) return false;
+            if(o.y >= R(0)) return false;
+            R odh = dot(o, h);
+            R J = -odh / sqr(eta * idh + odh);
+            R G = g.G2(i, o);
+            R D = g.D(h);
+            value = rgb(L.color2) * (idh * G * D * J * (R(1) - F) / (i.y * -o.y));
+            pdf_o = g.pdf(i, h) * J * (R(1) - F);
+            return true;
+        }
+        else if constexpr(TYPE == L_SPEC_GLASS)  // specular_glass.hpp:25-74
+        {
+            R cos_i = i.y;
+            R sin2_i = R(1) - cos_i * cos_i;
+            R sin_i = r_sqrt(sin2_i);
+            R eta = eta_a / eta_b;
+            R sin_t = eta * sin_i;
+            R cos_t = r_sqrt(R(1) - sin_t * sin_t);
+            R F = R(1);
+            if(sin_t < R(1))
+            {
+                R r_parl = ((eta_b * cos_i) - (eta_a * cos_t)) / ((eta_b * cos_i) + (eta_a * cos_t));
+                R r_perp = ((eta_a * cos_i) - (eta_b * cos_t)) / ((eta_a * cos_i) + (eta_b * cos_t));
+                F = (r_parl * r_parl + r_perp * r_perp) / R(2);
+            }
+            if(u1x < F)
+            {
+                o = vec3<R>{-i.x, i.y, -i.z};
+                value = rgb(L.color) * (F / o.y);
+                pdf_o = F;
+                return true;
+            }
+            o = eta * (-i);
+            o.y += eta * cos_i - cos_t;
+            value = rgb(L.color2) * ((R(1) - F) * (eta_b * eta_b) / (eta_a * eta_a * -o.y));
+            pdf_o = R(1) - F;
+            return true;
+        }
+        else if constexpr(TYPE == L_GGX_TRANS)  // microfacet_transmission.hpp:48-83
+        {
+            if(i.y == R(0)) return false;
+            Ggx<R> g{L.alpha[0], L.alpha[1]};
+            vec3<R> h = g.sample(i, u1x, u1y);
+            R idh = dot(i, h);
+            if(idh <= R(0)) return false;
+            R eta = eta_a / eta_b;
+            if(!refract(i, h, eta, o)) return false;
+            if(o.y >= R(0)) return false;
+            R odh = dot(o, h);
+            R J = -odh / sqr(eta * idh + odh);
+            value = rgb(L.color) * (idh * g.G2(i, o) * g.D(h) * J / (i.y * -o.y));
+            pdf_o = g.pdf(i, h) * J;
+            return true;
+        }
+        else  // L_SPEC_TRANS, specular_transmission.hpp:25-37
+        {
+            if(!refract(i, vec3<R>{R(0), R(1), R(0)}, eta_a / eta_b, o)) return false;
+            value = rgb(L.color) * ((eta_b * eta_b) / (eta_a * eta_a * -o.y));
+            pdf_o = R(1);
+            return true;
+        }
+    }
+
+    // ---------------------------------------------------------------- bsdf + bxdf_adapter
+    template<typename R>
+    struct ShadingFrame
+    {
+        vec3<R> t, ns, b, ng;
+        FC_HD vec3<R> to_local(vec3<R> w) const { return {dot(w, t), dot(w, ns), dot(w, b)}; }  // bsdf.hpp:156-163
+        FC_HD vec3<R> to_world(vec3<R> w) const                                                  // bsdf.hpp:165-172
+        {
+            return {t.x * w.x + ns.x * w.y + b.x * w.z, t.y * w.x + ns.y * w.y + b.y * w.z, t.z * w.x + ns.z * w.y + b.z * w.z};
+        }
+    };
+
+    // bsdf::evaluate, bsdf.hpp:62-72 over bxdf_adapter::evaluate, bxdf.hpp:57-67
+    template<int TYPE, typename R>
+    FC_HD vec3<R> bsdf_evaluate(const LobeRec<R>& L, const ShadingFrame<R>& f, vec3<R> wo, vec3<R> wi, R eta_a, R eta_b)
+    {
+        R wo_wg = dot(wo, f.ng), wo_ws = dot(wo, f.ns), wi_wg = dot(wi, f.ng), wi_ws = dot(wi, f.ns);
+        if(wo_wg * wo_ws <= R(0) || wi_wg * wi_ws <= R(0)) return vec3<R>{R(0), R(0), R(0)};
+        R c = r_abs(wi_ws) * L.factor / r_abs(wi_wg);
+        vec3<R> lo = f.to_local(wo), li = f.to_local(wi);
+        vec3<R> v = li.y >= R(0) ? lobe_evaluate<TYPE>(L, li, lo, eta_a, eta_b) : lobe_evaluate<TYPE>(L, -li, -lo, eta_b, eta_a);
+        return c * v;
+    }
+
+    // bsdf::pdf_wi, bsdf.hpp:131-141 over bxdf_adapter::pdf_wi, bxdf.hpp:117-127
+    template<int TYPE, typename R>
+    FC_HD R bsdf_pdf_wi(const LobeRec<R>& L, const ShadingFrame<R>& f, vec3<R> wo, vec3<R> wi, R eta_a, R eta_b)
+    {
+        R wo_wg = dot(wo, f.ng), wo_ws = dot(wo, f.ns), wi_wg = dot(wi, f.ng), wi_ws = dot(wi, f.ns);
+        if(wo_wg * wo_ws <= R(0) || wi_wg * wi_ws <= R(0)) return R(0);
+        vec3<R> lo = f.to_local(wo), li = f.to_local(wi);
+        return lo.y >= R(0) ? lobe_pdf<TYPE>(L, lo, li, eta_a, eta_b) : lobe_pdf<TYPE>(L, -lo, -li, eta_b, eta_a);
+    }
+
+    // bsdf::sample_wi, bsdf.hpp:74-100 over bxdf_adapter::sample_wi, bxdf.hpp:69-97
+    template<int TYPE, typename R>
+    FC_HD bool bsdf_sample_wi(const LobeRec<R>& L, const ShadingFrame<R>& f, vec3<R> wo, R eta_a, R eta_b,
+                              R u1x, R u1y, R u2x, R u2y, vec3<R>& wi, vec3<R>& value, R& pdf)
+    {
+        R wo_wg = dot(wo, f.ng), wo_ws = dot(wo, f.ns);
+        if(wo_wg * wo_ws <= R(0)) return false;
+        vec3<R> lo = f.to_local(wo);
+        vec3<R> li;
+        if(lo.y >= R(0))
+        {
+            if(!lobe_sample<TYPE>(L, lo, eta_a, eta_b, u1x, u1y, u2x, u2y, li, value, pdf)) return false;
+            if(li.y <= R(0)) value = value * ((eta_a * eta_a) / (eta_b * eta_b));
+        }
+        else
+        {
+            if(!lobe_sample<TYPE>(L, -lo, eta_b, eta_a, u1x, u1y, u2x, u2y, li, value, pdf)) return false;
+            li = -li;
+            if(li.y >= R(0)) value = value * ((eta_b * eta_b) / (eta_a * eta_a));
+        }
+        wi = f.to_world(li);
+        R wi_wg = dot(wi, f.ng), wi_ws = dot(wi, f.ns);
+        if(wi_wg * wi_ws <= R(0)) return false;
+        value = value * (r_abs(wi_ws) * L.factor / r_abs(wi_wg));
+        return true;
+    }
+
+    template<typename R> FC_HD R power_heuristic(R primary, R alternative)  // forward_mis_integrator.hpp:215-219
+    {
+        R x = alternative / primary;
+        return R(1) / (R(1) + x * x);
+    }
+}

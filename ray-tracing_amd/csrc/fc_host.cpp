@@ -1,0 +1,1038 @@
+// fc_host.cpp -- host-side scene flattening and BVH construction.
+//
+// What it replaces in the reference (all on the host, one-off, outside the timed region):
+//   * pr_transform / prs_transform matrix construction      src/core/transform.hpp:11-17, 72-82
+//   * mesh_surface's world-space vertex pre-transform        src/surfaces/mesh_surface.hpp:16-48
+//   * entity_scene's entity -> primitive flattening          src/core/scene.hpp:39-62
+//   * bvh_acceleration_structure's top-down SAH build        src/acceleration_structures/bvh_acceleration_structure.hpp:10-24, 228-365
+//   * material -> lobe list (the arena-allocated bsdf)        src/materials/*.hpp, src/core/bsdf.hpp:13-44
+//   * distribution_1d over emitter triangle areas            src/core/distribution.hpp:32-60
+// The binary tree is built with the reference's algorithm (same buckets, same costs, same
+// std::nth_element / std::partition calls) and then collapsed into the 4-wide quantised
+// layout of fc_types.h, which is what the device traverses.
+#include "fc_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace fcg
+{
+    namespace
+    {
+        // ------------------------------------------------------------ double-precision transforms
+        struct M4
+        {
+            double m[4][4];
+        };
+
+        M4 identity()
+        {
+            M4 r{};
+            for(int i = 0; i < 4; ++i) r.m[i][i] = 1.0;
+            return r;
+        }
+        M4 mul(const M4& a, const M4& b)
+        {
+            M4 c{};
+            for(int i = 0; i < 4; ++i)
+                for(int j = 0; j < 4; ++j)
+                    c.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j] + a.m[i][3] * b.m[3][j];
+            return c;
+        }
+        M4 translate(const double* t, double sign)
+        {
+            M4 r = identity();
+            r.m[0][3] = sign * t[0];
+            r.m[1][3] = sign * t[1];
+            r.m[2][3] = sign * t[2];
+            return r;
+        }
+        M4 scale3(double x, double y, double z)
+        {
+            M4 r = identity();
+            r.m[0][0] = x;
+            r.m[1][1] = y;
+            r.m[2][2] = z;
+            return r;
+        }
+        M4 rot_x(double th)
+        {
+            double s = std::sin(th), c = std::cos(th);
+            M4 r = identity();
+            r.m[1][1] = c; r.m[1][2] = -s;
+            r.m[2][1] = s; r.m[2][2] = c;
+            return r;
+        }
+        M4 rot_y(double th)
+        {
+            double s = std::sin(th), c = std::cos(th);
+            M4 r = identity();
+            r.m[0][0] = c; r.m[0][2] = s;
+            r.m[2][0] = -s; r.m[2][2] = c;
+            return r;
+        }
+        M4 rot_z(double th)
+        {
+            double s = std::sin(th), c = std::cos(th);
+            M4 r = identity();
+            r.m[0][0] = c; r.m[0][1] = -s;
+            r.m[1][0] = s; r.m[1][1] = c;
+            return r;
+        }
+
+        struct Xf
+        {
+            M4 t, inv;
+        };
+
+        // transform.hpp:14-17 (pr) and :79-82 (prs). The reference's single-argument and
+        // two-argument constructors produce the same matrices as the general product with
+        // zero rotation / unit scale up to the sign of zero, so one routine serves all three.
+        Xf make_xf(const double* pos, const double* rot, const double* scl)
+        {
+            Xf x;
+            bool has_rot = rot[0] != 0.0 || rot[1] != 0.0 || rot[2] != 0.0;
+            bool has_scl = scl != nullptr && (scl[0] != 1.0 || scl[1] != 1.0 || scl[2] != 1.0);
+            if(!has_rot && !has_scl)
+            {
+                x.t = translate(pos, 1.0);
+                x.inv = translate(pos, -1.0);
+                return x;
+            }
+            x.t = mul(mul(mul(translate(pos, 1.0), rot_y(rot[1])), rot_x(rot[0])), rot_z(rot[2]));
+            x.inv = mul(mul(mul(rot_z(-rot[2]), rot_x(-rot[0])), rot_y(-rot[1])), translate(pos, -1.0));
+            if(has_scl)
+            {
+                x.t = mul(x.t, scale3(scl[0], scl[1], scl[2]));
+                x.inv = mul(scale3(1.0 / scl[0], 1.0 / scl[1], 1.0 / scl[2]), x.inv);
+            }
+            return x;
+        }
+
+        struct D3
+        {
+            double x, y, z;
+        };
+        D3 xpoint(const M4& m, D3 p)
+        {
+            return {m.m[0][0] * p.x + m.m[0][1] * p.y + m.m[0][2] * p.z + m.m[0][3],
+                    m.m[1][0] * p.x + m.m[1][1] * p.y + m.m[1][2] * p.z + m.m[1][3],
+                    m.m[2][0] * p.x + m.m[2][1] * p.y + m.m[2][2] * p.z + m.m[2][3]};
+        }
+        // prs_transform::transform_normal, transform.hpp:100-106 (transpose of the inverse, normalised)
+        D3 xnormal(const M4& inv, D3 n)
+        {
+            double x = inv.m[0][0] * n.x + inv.m[1][0] * n.y + inv.m[2][0] * n.z;
+            double y = inv.m[0][1] * n.x + inv.m[1][1] * n.y + inv.m[2][1] * n.z;
+            double z = inv.m[0][2] * n.x + inv.m[1][2] * n.y + inv.m[2][2] * n.z;
+            double len = std::sqrt(x * x + y * y + z * z);
+            return {x / len, y / len, z / len};
+        }
+
+        // ------------------------------------------------------------ float bounds (bounds3f)
+        struct BoxF
+        {
+            float lo[3]{std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+            float hi[3]{std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest()};
+
+            void grow(const float* p)
+            {
+                for(int i = 0; i < 3; ++i)
+                {
+                    lo[i] = std::min(lo[i], p[i]);
+                    hi[i] = std::max(hi[i], p[i]);
+                }
+            }
+            void grow(const BoxF& b)
+            {
+                for(int i = 0; i < 3; ++i)
+                {
+                    lo[i] = std::min(lo[i], b.lo[i]);
+                    hi[i] = std::max(hi[i], b.hi[i]);
+                }
+            }
+            float area() const  // math.hpp:607-611
+            {
+                float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+                return 2.0f * (dx * dy + dx * dz + dy * dz);
+            }
+            int max_extent() const  // math.hpp:590-605
+            {
+                float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+                if(dx > dy && dx > dz) return 0;
+                if(dy > dz) return 1;
+                return 2;
+            }
+        };
+
+        // pr_transform::transform_bounds of a local box, rounded to float (math.hpp:544-547)
+        BoxF transformed_box(const M4& t, D3 lo, D3 hi)
+        {
+            double mn[3]{1e300, 1e300, 1e300}, mx[3]{-1e300, -1e300, -1e300};
+            for(int c = 0; c < 8; ++c)
+            {
+                // TBounds3::Corner, math.hpp:575-578
+                D3 p{(c & 1) ? hi.x : lo.x, (c & 4) ? hi.y : lo.y, (c & 2) ? hi.z : lo.z};
+                D3 q = xpoint(t, p);
+                mn[0] = std::min(mn[0], q.x); mn[1] = std::min(mn[1], q.y); mn[2] = std::min(mn[2], q.z);
+                mx[0] = std::max(mx[0], q.x); mx[1] = std::max(mx[1], q.y); mx[2] = std::max(mx[2], q.z);
+            }
+            BoxF b;
+            for(int i = 0; i < 3; ++i)
+            {
+                b.lo[i] = static_cast<float>(mn[i]);
+                b.hi[i] = static_cast<float>(mx[i]);
+            }
+            return b;
+        }
+
+        // ------------------------------------------------------------ binary SAH build
+        struct PrimRef  // primitive_info, bvh_acceleration_structure.hpp:200-226
+        {
+            uint32_t index;
+            BoxF box;
+            float centroid[3];
+        };
+
+        struct BinNode
+        {
+            BoxF box;
+            uint32_t a;         // leaf: first primitive in `order`; interior: second child
+            uint16_t b;         // leaf: primitive count; interior: split axis
+            uint16_t interior;
+        };
+
+        struct BinaryBvh
+        {
+            std::vector<BinNode> nodes;
+            std::vector<uint32_t> order;  // primitive indices in leaf order
+        };
+
+        class BinaryBuilder
+        {
+        public:
+            BinaryBuilder(std::vector<PrimRef>& refs, BinaryBvh& out) : refs_{refs}, out_{out} {}
+
+            uint32_t build(uint32_t begin, uint32_t end)  // :228-245
+            {
+                BoxF box = refs_[begin].box;
+                for(uint32_t i = begin + 1; i < end; ++i) box.grow(refs_[i].box);
+                if(end - begin == 1) return leaf(begin, end, box);
+                return interior(begin, end, box);
+            }
+
+        private:
+            std::vector<PrimRef>& refs_;
+            BinaryBvh& out_;
+
+            uint32_t leaf(uint32_t begin, uint32_t end, const BoxF& box)  // :247-260
+            {
+                uint32_t first = static_cast<uint32_t>(out_.order.size());
+                for(uint32_t i = begin; i < end; ++i) out_.order.push_back(refs_[i].index);
+                uint32_t index = static_cast<uint32_t>(out_.nodes.size());
+                out_.nodes.push_back(BinNode{box, first, static_cast<uint16_t>(end - begin), 0});
+                return index;
+            }
+
+            uint32_t interior(uint32_t begin, uint32_t end, const BoxF& box)  // :262-365
+            {
+                BoxF cb;
+                for(int k = 0; k < 3; ++k) cb.lo[k] = cb.hi[k] = refs_[begin].centroid[k];
+                for(uint32_t i = begin + 1; i < end; ++i) cb.grow(refs_[i].centroid);
+
+                int axis = cb.max_extent();
+                float axis_length = cb.hi[axis] - cb.lo[axis];
+                if(axis_length == 0.0f) return leaf(begin, end, box);
+
+                uint32_t count = end - begin;
+                uint32_t middle = begin + count / 2;
+                if(count <= 4)
+                {
+                    std::nth_element(refs_.begin() + begin, refs_.begin() + middle, refs_.begin() + end,
+                                     [axis](const PrimRef& a, const PrimRef& b) { return a.centroid[axis] < b.centroid[axis]; });
+                }
+                else
+                {
+                    constexpr int bucket_count = 12;
+                    struct Bucket
+                    {
+                        uint32_t count{};
+                        BoxF box{};
+                    };
+                    Bucket buckets[bucket_count]{};
+                    for(uint32_t i = begin; i < end; ++i)
+                    {
+                        float offset = (refs_[i].centroid[axis] - cb.lo[axis]) / axis_length;
+                        int bi = std::min(static_cast<int>(offset * bucket_count), bucket_count - 1);
+                        buckets[bi].count += 1;
+                        buckets[bi].box.grow(refs_[i].box);
+                    }
+                    double costs[bucket_count - 1]{};
+                    for(int i = 0; i < bucket_count - 1; ++i)
+                    {
+                        Bucket b0{}, b1{};
+                        for(int j = 0; j <= i; ++j)
+                        {
+                            b0.box.grow(buckets[j].box);
+                            b0.count += buckets[j].count;
+                        }
+                        for(int j = i + 1; j < bucket_count; ++j)
+                        {
+                            b1.box.grow(buckets[j].box);
+                            b1.count += buckets[j].count;
+                        }
+                        costs[i] = 0.125 + (b0.count * b0.box.area() + b1.count * b1.box.area()) / box.area();
+                    }
+                    double min_cost = costs[0];
+                    int min_index = 0;
+                    for(int i = 1; i < bucket_count - 1; ++i)
+                    {
+                        if(costs[i] < min_cost)
+                        {
+                            min_cost = costs[i];
+                            min_index = i;
+                        }
+                    }
+                    double leaf_cost = static_cast<double>(count);
+                    if(min_cost < leaf_cost)
+                    {
+                        float partition_point = cb.lo[axis] + axis_length / bucket_count * (min_index + 1);
+                        auto it = std::partition(refs_.begin() + begin, refs_.begin() + end,
+                                                 [axis, partition_point](const PrimRef& a) { return a.centroid[axis] < partition_point; });
+                        middle = static_cast<uint32_t>(std::distance(refs_.begin(), it));
+                    }
+                    else
+                    {
+                        return leaf(begin, end, box);
+                    }
+                }
+
+                uint32_t index = static_cast<uint32_t>(out_.nodes.size());
+                out_.nodes.emplace_back();
+                build(begin, middle);
+                uint32_t right = build(middle, end);
+                out_.nodes[index] = BinNode{box, right, static_cast<uint16_t>(axis), 1};
+                return index;
+            }
+        };
+
+        // ------------------------------------------------------------ 4-wide collapse + quantisation
+        struct WideChild
+        {
+            BoxF box;
+            bool leaf;
+            uint32_t bin;    // binary node (interior child)
+            uint32_t first;  // leaf: range in leaf_prims
+            uint32_t count;
+        };
+
+        class WideBuilder
+        {
+        public:
+            WideBuilder(const BinaryBvh& bin, const std::vector<uint32_t>& prim_kind_index, FlatScene& out)
+                : bin_{bin}, kind_index_{prim_kind_index}, out_{out}
+            {
+            }
+
+            void run()
+            {
+                // leaf_prims follows the binary leaf order, so a binary leaf [a, a+b) is the same range
+                out_.leaf_prims.resize(bin_.order.size());
+                for(size_t i = 0; i < bin_.order.size(); ++i) out_.leaf_prims[i] = kind_index_[bin_.order[i]];
+                std::vector<WideChild> kids;
+                gather(0, kids);
+                out_.max_stack = emit(kids);
+            }
+
+        private:
+            const BinaryBvh& bin_;
+            const std::vector<uint32_t>& kind_index_;
+            FlatScene& out_;
+
+            void push_bin(uint32_t b, std::vector<WideChild>& kids, size_t at)
+            {
+                const BinNode& n = bin_.nodes[b];
+                if(n.interior)
+                {
+                    kids.insert(kids.begin() + at, WideChild{n.box, false, b, 0, 0});
+                    return;
+                }
+                // a binary leaf wider than MAX_LEAF_PRIMS is cut into runs
+                uint32_t first = n.a, left = n.b;
+                std::vector<WideChild> runs;
+                while(left > 0)
+                {
+                    uint32_t c = std::min<uint32_t>(left, MAX_LEAF_PRIMS);
+                    runs.push_back(WideChild{n.box, true, 0, first, c});
+                    first += c;
+                    left -= c;
+                }
+                kids.insert(kids.begin() + at, runs.begin(), runs.end());
+            }
+
+            // children of binary node b, opened until four (largest surface area first)
+            void gather(uint32_t b, std::vector<WideChild>& kids)
+            {
+                kids.clear();
+                const BinNode& n = bin_.nodes[b];
+                if(!n.interior)
+                {
+                    push_bin(b, kids, 0);
+                    return;
+                }
+                push_bin(b + 1, kids, 0);
+                push_bin(n.a, kids, kids.size());
+                while(kids.size() < 4)
+                {
+                    int best = -1;
+                    float best_area = -1.0f;
+                    for(size_t i = 0; i < kids.size(); ++i)
+                    {
+                        if(!kids[i].leaf && kids[i].box.area() > best_area)
+                        {
+                            best_area = kids[i].box.area();
+                            best = static_cast<int>(i);
+                        }
+                    }
+                    if(best < 0) break;
+                    uint32_t bb = kids[best].bin;
+                    kids.erase(kids.begin() + best);
+                    const BinNode& nb = bin_.nodes[bb];
+                    size_t before = kids.size();
+                    push_bin(bb + 1, kids, best);
+                    size_t added = kids.size() - before;
+                    push_bin(nb.a, kids, best + added);
+                    if(kids.size() > 4) break;  // only through wide-leaf runs; emit() groups the surplus
+                }
+            }
+
+            // writes one wide node for `kids` (grouping surplus children under extra nodes) and
+            // returns the worst-case stack depth needed below it
+            uint32_t emit(std::vector<WideChild> kids)
+            {
+                while(kids.size() > 4)
+                {
+                    // fold the trailing children into a sub-node (only for oversized leaves)
+                    std::vector<WideChild> tail(kids.end() - 4, kids.end());
+                    kids.erase(kids.end() - 4, kids.end());
+                    BoxF b;
+                    for(auto& k : tail) b.grow(k.box);
+                    pending_.push_back(std::move(tail));
+                    kids.push_back(WideChild{b, false, INVALID_U32, static_cast<uint32_t>(pending_.size() - 1), 0});
+                }
+
+                uint32_t index = static_cast<uint32_t>(out_.nodes.size());
+                out_.nodes.emplace_back();
+                BoxF box;
+                for(auto& k : kids) box.grow(k.box);
+
+                Node4 node{};
+                quantise(box, kids, node);
+                uint32_t deepest = 0;
+                for(size_t c = 0; c < 4; ++c)
+                {
+                    if(c >= kids.size())
+                    {
+                        node.child[c] = INVALID_U32;
+                        continue;
+                    }
+                    const WideChild& k = kids[c];
+                    if(k.leaf)
+                    {
+                        node.child[c] = NODE_LEAF_BIT | ((k.count - 1) << 27) | k.first;
+                    }
+                    else
+                    {
+                        node.child[c] = static_cast<uint32_t>(out_.nodes.size());
+                        std::vector<WideChild> sub;
+                        if(k.bin == INVALID_U32)
+                            sub = pending_[k.first];
+                        else
+                            gather(k.bin, sub);
+                        deepest = std::max(deepest, emit(std::move(sub)));
+                    }
+                }
+                node.n = static_cast<uint8_t>(kids.size());
+                out_.nodes[index] = node;
+                // while one child is being traversed at most (n - 1) siblings wait on the stack
+                return static_cast<uint32_t>(kids.size() - 1) + deepest;
+            }
+
+            std::vector<std::vector<WideChild>> pending_;
+
+            static void quantise(const BoxF& box, const std::vector<WideChild>& kids, Node4& node)
+            {
+                node.ox = box.lo[0];
+                node.oy = box.lo[1];
+                node.oz = box.lo[2];
+                uint8_t* ebytes[3]{&node.ex, &node.ey, &node.ez};
+                for(int a = 0; a < 3; ++a)
+                {
+                    float extent = box.hi[a] - box.lo[a];
+                    int e = -100;
+                    if(extent > 0.0f)
+                    {
+                        e = static_cast<int>(std::ceil(std::log2(static_cast<double>(extent) / 255.0)));
+                    }
+                    e = std::max(e, -120);
+                    for(;;)
+                    {
+                        float step = std::ldexp(1.0f, e);
+                        bool ok = true;
+                        uint32_t lo_word = 0, hi_word = 0;
+                        for(size_t c = 0; c < 4 && ok; ++c)
+                        {
+                            uint32_t ql = 255, qh = 0;  // empty slot: inverted interval
+                            if(c < kids.size())
+                            {
+                                double rl = (static_cast<double>(kids[c].box.lo[a]) - box.lo[a]) / step;
+                                double rh = (static_cast<double>(kids[c].box.hi[a]) - box.lo[a]) / step;
+                                long l = static_cast<long>(std::floor(rl));
+                                long h = static_cast<long>(std::ceil(rh));
+                                l = std::max(0l, l);
+                                // conservative under the device's fp32 decode (fma(q, step, origin))
+                                while(l > 0 && std::fmaf(static_cast<float>(l), step, box.lo[a]) > kids[c].box.lo[a]) --l;
+                                while(h <= 255 && std::fmaf(static_cast<float>(h), step, box.lo[a]) < kids[c].box.hi[a]) ++h;
+                                if(h > 255 || l > 255) ok = false;
+                                ql = static_cast<uint32_t>(l);
+                                qh = static_cast<uint32_t>(h);
+                            }
+                            lo_word |= ql << (8 * c);
+                            hi_word |= qh << (8 * c);
+                        }
+                        if(ok)
+                        {
+                            node.qlo[a] = lo_word;
+                            node.qhi[a] = hi_word;
+                            *ebytes[a] = static_cast<uint8_t>(e + 127);
+                            break;
+                        }
+                        ++e;
+                    }
+                }
+            }
+        };
+
+        // ------------------------------------------------------------ typed conversion
+        template<typename R> void put12(R* dst, const M4& m)
+        {
+            for(int i = 0; i < 3; ++i)
+                for(int j = 0; j < 4; ++j) dst[i * 4 + j] = static_cast<R>(m.m[i][j]);
+        }
+
+        struct LobeD  // lobe in double, converted per precision
+        {
+            int type, fresnel;
+            double color[3], color2[3], alpha[2], ior, factor, cdf;
+        };
+
+        double rough_to_alpha(double r)  // microfacet.hpp:76-81
+        {
+            double x = std::max(r, 0.002);
+            return x * x;
+        }
+
+        // materials -> lobes, mirroring material::evaluate of each class with constant textures
+        int material_lobes(const fcgpu_material& m, std::vector<LobeD>& lobes, std::string& err)
+        {
+            struct Pending
+            {
+                LobeD lobe;
+                double scale, weight;
+            };
+            std::vector<Pending> ps;
+            auto base = [&](int type, int fresnel, const double* c, const double* c2, const double* rough, double ior)
+            {
+                LobeD l{};
+                l.type = type;
+                l.fresnel = fresnel;
+                for(int i = 0; i < 3; ++i)
+                {
+                    l.color[i] = c ? c[i] : 0.0;
+                    l.color2[i] = c2 ? c2[i] : 0.0;
+                }
+                l.alpha[0] = rough_to_alpha(rough ? rough[0] : 0.0);
+                l.alpha[1] = rough_to_alpha(rough ? rough[1] : 0.0);
+                l.ior = ior;
+                return l;
+            };
+            bool smooth = m.roughness[0] == 0.0 && m.roughness[1] == 0.0;
+            const double one[3]{1.0, 1.0, 1.0};
+            switch(m.kind)
+            {
+            case FCGPU_MATERIAL_DIFFUSE:  // diffuse_material.hpp:29-37
+                ps.push_back({base(L_LAMBERT, 0, m.color_a, nullptr, nullptr, 0.0), 1.0, 1.0});
+                break;
+            case FCGPU_MATERIAL_MIRROR:  // mirror_material.hpp:38-55
+                ps.push_back({base(smooth ? L_SPEC_REFL : L_GGX_REFL, 0, m.color_a, nullptr, m.roughness, 0.0), 1.0, 1.0});
+                break;
+            case FCGPU_MATERIAL_GLASS:  // glass_material.hpp:29-40
+                ps.push_back({base(smooth ? L_SPEC_GLASS : L_GGX_GLASS, 0, m.color_a, m.color_b, m.roughness, 0.0), 1.0, 1.0});
+                break;
+            case FCGPU_MATERIAL_PLASTIC:  // plastic_material.hpp:26-51
+                ps.push_back({base(L_LAMBERT, 0, m.color_a, nullptr, nullptr, 0.0), 1.0, 1.0});
+                ps.push_back({base(smooth ? L_SPEC_REFL : L_GGX_REFL, 1, m.color_b, nullptr, m.roughness, m.ior), 1.0, 1.0});
+                break;
+            case FCGPU_MATERIAL_STANDARD:  // standard_material.hpp:49-103
+            {
+                double r2[2]{m.roughness[0], m.roughness[0]};
+                bool sm = m.roughness[0] == 0.0;
+                if(m.metalness < 1.0)
+                {
+                    double s = 1.0 - m.metalness, w = (1.0 - m.metalness) / 2.0;
+                    ps.push_back({base(L_LAMBERT, 0, m.color_a, nullptr, nullptr, 0.0), s, w});
+                    ps.push_back({base(sm ? L_SPEC_REFL : L_GGX_REFL, 1, one, nullptr, r2, m.ior), s, w});
+                }
+                if(m.metalness > 0.0)
+                {
+                    ps.push_back({base(sm ? L_SPEC_REFL : L_GGX_REFL, 0, m.color_a, nullptr, r2, 0.0), m.metalness, m.metalness});
+                }
+                break;
+            }
+            case FCGPU_MATERIAL_TRANSMISSION:  // transmission_material.hpp:28-39
+                ps.push_back({base(smooth ? L_SPEC_TRANS : L_GGX_TRANS, 0, m.color_b, nullptr, m.roughness, 0.0), 1.0, 1.0});
+                break;
+            default:
+                err = "unknown material kind";
+                return FCGPU_E_INVALID;
+            }
+            // bsdf constructor, bsdf.hpp:30-43
+            double weight_sum = 0.0;
+            for(auto& p : ps) weight_sum += p.weight;
+            double prefix = 0.0;
+            for(size_t i = 0; i < ps.size(); ++i)
+            {
+                double pdf = ps[i].weight / weight_sum;
+                ps[i].lobe.factor = ps[i].scale / pdf;
+                ps[i].lobe.cdf = i == 0 ? 0.0 : prefix;
+                // weight[i] = weight[i-1] + pdf[i-1], accumulated left to right as the reference does
+                prefix = (i == 0 ? 0.0 : prefix) + pdf;
+                lobes.push_back(ps[i].lobe);
+            }
+            return (int)ps.size();
+        }
+
+        template<typename R>
+        void convert_lobes(const std::vector<LobeD>& src, std::vector<LobeRec<R>>& dst)
+        {
+            for(const LobeD& l : src)
+            {
+                LobeRec<R> r{};
+                r.type = l.type;
+                r.fresnel = l.fresnel;
+                for(int i = 0; i < 3; ++i)
+                {
+                    r.color[i] = static_cast<R>(l.color[i]);
+                    r.color2[i] = static_cast<R>(l.color2[i]);
+                }
+                r.alpha[0] = static_cast<R>(l.alpha[0]);
+                r.alpha[1] = static_cast<R>(l.alpha[1]);
+                r.ior = static_cast<R>(l.ior);
+                r.factor = static_cast<R>(l.factor);
+                r.cdf = l.cdf;
+                dst.push_back(r);
+            }
+        }
+
+        struct XPrimD
+        {
+            Xf xf;
+            double a, b, inv_area;
+            uint32_t prim, entity;
+        };
+        template<typename R>
+        void convert_xprims(const std::vector<XPrimD>& src, std::vector<XPrim<R>>& dst)
+        {
+            for(const XPrimD& s : src)
+            {
+                XPrim<R> x{};
+                put12(x.inv, s.xf.inv);
+                put12(x.fwd, s.xf.t);
+                x.a = static_cast<R>(s.a);
+                x.b = static_cast<R>(s.b);
+                x.prim = s.prim;
+                x.entity = s.entity;
+                x.inv_area = static_cast<R>(s.inv_area);
+                dst.push_back(x);
+            }
+        }
+
+        struct LightD
+        {
+            int32_t entity;
+            uint32_t kind, index, first_prim, tri_count, cdf_offset;
+            double Le[3], inv_area;
+        };
+        template<typename R>
+        void convert_lights(const std::vector<LightD>& src, std::vector<LightRec<R>>& dst)
+        {
+            for(const LightD& s : src)
+            {
+                LightRec<R> l{};
+                l.entity = s.entity;
+                l.kind = s.kind;
+                l.index = s.index;
+                l.first_prim = s.first_prim;
+                l.tri_count = s.tri_count;
+                l.cdf_offset = s.cdf_offset;
+                for(int i = 0; i < 3; ++i) l.Le[i] = static_cast<R>(s.Le[i]);
+                l.inv_area = static_cast<R>(s.inv_area);
+                dst.push_back(l);
+            }
+        }
+
+        template<typename R>
+        void convert_camera(const fcgpu_camera& c, CameraRec<R>& out)
+        {
+            const double zero[3]{0, 0, 0};
+            (void)zero;
+            Xf xf = make_xf(c.position, c.rotation, nullptr);
+            put12(out.fwd, xf.t);
+            // perspective_camera.hpp:19-27
+            double focus = c.lens_radius == 0.0 ? 1.0 : c.focus_distance;
+            double pixel = 2.0 * focus * std::tan(c.fov / 2.0) / static_cast<double>(c.height);
+            out.plane_w = static_cast<R>(c.width * pixel);
+            out.plane_h = static_cast<R>(c.height * pixel);
+            out.focus = static_cast<R>(focus);
+            out.lens_radius = static_cast<R>(c.lens_radius);
+            out.W = c.width;
+            out.H = c.height;
+        }
+    }  // namespace
+
+    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err)
+    {
+        out = FlatScene{};
+        if(d.entity_count == 0 || d.surface_count == 0 || d.material_count == 0)
+        {
+            err = "scene needs at least one entity, surface and material";
+            return FCGPU_E_INVALID;
+        }
+        if(d.camera.width <= 0 || d.camera.height <= 0 || d.camera.width >= (1 << 20) || d.camera.height >= (1 << 20))
+        {
+            err = "camera resolution out of range";
+            return FCGPU_E_INVALID;
+        }
+        if(d.medium_count > static_cast<uint32_t>(MAX_MEDIA))
+        {
+            err = "more than 15 media";
+            return FCGPU_E_LIMIT;
+        }
+        out.width = d.camera.width;
+        out.height = d.camera.height;
+
+        // ---- materials
+        std::vector<LobeD> lobes;
+        for(uint32_t i = 0; i < d.material_count; ++i)
+        {
+            int first = static_cast<int>(lobes.size());
+            int n = material_lobes(d.materials[i], lobes, err);
+            if(n < 0) return n;
+            out.materials.push_back(MaterialRec{first, n});
+        }
+        for(const LobeD& l : lobes) out.lobe_mask |= 1u << l.type;
+        convert_lobes(lobes, out.f32.lobes);
+        convert_lobes(lobes, out.f64.lobes);
+
+        // ---- media (index 0 = the helper's dummy vacuum, integrator.hpp:115)
+        auto push_medium = [&](int prio, double ior, double sx, double sy, double sz)
+        {
+            MediumRec<float> a{prio, 0, (float)ior, {(float)sx, (float)sy, (float)sz}};
+            MediumRec<double> b{prio, 0, ior, {sx, sy, sz}};
+            out.f32.media.push_back(a);
+            out.f64.media.push_back(b);
+        };
+        push_medium(-1, 1.0, 0.0, 0.0, 0.0);
+        for(uint32_t i = 0; i < d.medium_count; ++i)
+        {
+            const fcgpu_medium& m = d.media[i];
+            // -color * density folded; the sign is applied on the device (medium.hpp:49)
+            push_medium(m.priority, m.ior, m.color[0] * m.density, m.color[1] * m.density, m.color[2] * m.density);
+        }
+
+        // ---- surfaces -> primitives (entity order, scene.hpp:49-55)
+        std::vector<XPrimD> xprims;
+        std::vector<LightD> lights;
+        std::vector<PrimRef> refs;
+        std::vector<uint32_t> kind_index;  // per global primitive
+        std::vector<TriRec> tris_orig;     // per triangle, original order; re-ordered after the build
+        std::vector<TriAttr> attrs;
+
+        for(uint32_t ei = 0; ei < d.entity_count; ++ei)
+        {
+            const fcgpu_entity& e = d.entities[ei];
+            if(e.surface < 0 || static_cast<uint32_t>(e.surface) >= d.surface_count || e.material < 0 ||
+               static_cast<uint32_t>(e.material) >= d.material_count || e.medium >= static_cast<int32_t>(d.medium_count))
+            {
+                err = "entity references out of range";
+                return FCGPU_E_INVALID;
+            }
+            const fcgpu_surface& s = d.surfaces[e.surface];
+            EntityRec er{};
+            er.material = e.material;
+            er.medium = e.medium < 0 ? 0 : e.medium + 1;
+            er.light = -1;
+            er.flags = (s.kind == FCGPU_SURFACE_MESH && s.has_normals ? 1u : 0u) | (s.kind == FCGPU_SURFACE_MESH && s.has_uvs ? 2u : 0u);
+
+            uint32_t first_prim = static_cast<uint32_t>(kind_index.size());
+            LightD light{};
+            light.entity = static_cast<int32_t>(ei);
+            light.first_prim = first_prim;
+            for(int k = 0; k < 3; ++k) light.Le[k] = e.emission_color[k] * e.emission_strength;
+
+            if(s.kind == FCGPU_SURFACE_SPHERE || s.kind == FCGPU_SURFACE_PLANE)
+            {
+                if(s.scale[0] != 1.0 || s.scale[1] != 1.0 || s.scale[2] != 1.0)
+                {
+                    err = "sphere / plane surfaces take a pr_transform (no scale)";
+                    return FCGPU_E_INVALID;
+                }
+                XPrimD x{};
+                x.xf = make_xf(s.position, s.rotation, nullptr);
+                x.prim = first_prim;
+                x.entity = ei;
+                BoxF box;
+                if(s.kind == FCGPU_SURFACE_SPHERE)
+                {
+                    x.a = s.radius;
+                    x.inv_area = 1.0 / (4.0 * 3.141592653589793 * s.radius * s.radius);  // sphere_surface.hpp:31-34,170
+                    box = transformed_box(x.xf.t, {-s.radius, -s.radius, -s.radius}, {s.radius, s.radius, s.radius});
+                    light.kind = KIND_SPHERE;
+                }
+                else
+                {
+                    x.a = s.size[0];
+                    x.b = s.size[1];
+                    x.inv_area = 1.0 / (s.size[0] * s.size[1]);  // plane_surface.hpp:30-33,129
+                    box = transformed_box(x.xf.t, {-s.size[0] / 2.0, 0.0, -s.size[1] / 2.0}, {s.size[0] / 2.0, 0.0, s.size[1] / 2.0});
+                    light.kind = KIND_PLANE;
+                }
+                uint32_t xi = static_cast<uint32_t>(xprims.size());
+                light.index = xi;
+                light.inv_area = x.inv_area;
+                xprims.push_back(x);
+                uint32_t kind = s.kind == FCGPU_SURFACE_SPHERE ? KIND_SPHERE : KIND_PLANE;
+                kind_index.push_back((kind << 30) | xi);
+                PrimRef r{};
+                r.index = first_prim;
+                r.box = box;
+                for(int k = 0; k < 3; ++k) r.centroid[k] = box.lo[k] * 0.5f + box.hi[k] * 0.5f;  // math.hpp:580-583
+                refs.push_back(r);
+                out.prim_info.push_back(PrimInfo{(kind << 30) | xi, ei});
+            }
+            else if(s.kind == FCGPU_SURFACE_MESH)
+            {
+                if(s.index_count % 3 != 0 || s.index_count == 0 || s.vertex_count == 0 ||
+                   static_cast<uint64_t>(s.vertex_offset) + s.vertex_count > d.vertex_total ||
+                   static_cast<uint64_t>(s.index_offset) + s.index_count > d.index_total || d.positions == nullptr || d.indices == nullptr)
+                {
+                    err = "mesh ranges out of bounds";
+                    return FCGPU_E_INVALID;
+                }
+                Xf xf = make_xf(s.position, s.rotation, s.scale);
+                // mesh_surface.hpp:23-38: transform in double, store float
+                std::vector<float> wp(3 * static_cast<size_t>(s.vertex_count));
+                std::vector<float> wn;
+                for(uint32_t v = 0; v < s.vertex_count; ++v)
+                {
+                    const float* p = d.positions + 3 * static_cast<size_t>(s.vertex_offset + v);
+                    D3 q = xpoint(xf.t, {p[0], p[1], p[2]});
+                    wp[3 * v + 0] = static_cast<float>(q.x);
+                    wp[3 * v + 1] = static_cast<float>(q.y);
+                    wp[3 * v + 2] = static_cast<float>(q.z);
+                }
+                if(s.has_normals)
+                {
+                    if(d.normals == nullptr)
+                    {
+                        err = "mesh has_normals but no normals pool";
+                        return FCGPU_E_INVALID;
+                    }
+                    wn.resize(wp.size());
+                    for(uint32_t v = 0; v < s.vertex_count; ++v)
+                    {
+                        const float* p = d.normals + 3 * static_cast<size_t>(s.vertex_offset + v);
+                        D3 q = xnormal(xf.inv, {p[0], p[1], p[2]});
+                        wn[3 * v + 0] = static_cast<float>(q.x);
+                        wn[3 * v + 1] = static_cast<float>(q.y);
+                        wn[3 * v + 2] = static_cast<float>(q.z);
+                    }
+                }
+                if(s.has_uvs && d.uvs == nullptr)
+                {
+                    err = "mesh has_uvs but no uv pool";
+                    return FCGPU_E_INVALID;
+                }
+                uint32_t ntri = s.index_count / 3;
+                double area_total = 0.0;
+                std::vector<double> areas(ntri);
+                for(uint32_t t = 0; t < ntri; ++t)
+                {
+                    const uint32_t* ix = d.indices + s.index_offset + 3 * static_cast<size_t>(t);
+                    if(ix[0] >= s.vertex_count || ix[1] >= s.vertex_count || ix[2] >= s.vertex_count)
+                    {
+                        err = "mesh index out of range";
+                        return FCGPU_E_INVALID;
+                    }
+                    TriRec tr{};
+                    const float* v[3]{&wp[3 * ix[0]], &wp[3 * ix[1]], &wp[3 * ix[2]]};
+                    std::memcpy(tr.v0, v[0], 12);
+                    std::memcpy(tr.v1, v[1], 12);
+                    std::memcpy(tr.v2, v[2], 12);
+                    uint32_t prim = first_prim + t;
+                    tr.prim = prim;
+                    tr.entity = ei;
+                    tr.attr = INVALID_U32;
+                    if(s.has_normals || s.has_uvs)
+                    {
+                        TriAttr a{};
+                        // defaults of mesh_surface.hpp:348-351 when the mesh has no uvs
+                        a.uv0[0] = 0; a.uv0[1] = 0; a.uv1[0] = 1; a.uv1[1] = 0; a.uv2[0] = 1; a.uv2[1] = 1;
+                        if(s.has_normals)
+                        {
+                            std::memcpy(a.n0, &wn[3 * ix[0]], 12);
+                            std::memcpy(a.n1, &wn[3 * ix[1]], 12);
+                            std::memcpy(a.n2, &wn[3 * ix[2]], 12);
+                        }
+                        if(s.has_uvs)
+                        {
+                            const float* u = d.uvs + 2 * static_cast<size_t>(s.vertex_offset);
+                            std::memcpy(a.uv0, u + 2 * ix[0], 8);
+                            std::memcpy(a.uv1, u + 2 * ix[1], 8);
+                            std::memcpy(a.uv2, u + 2 * ix[2], 8);
+                        }
+                        tr.attr = static_cast<uint32_t>(attrs.size());
+                        attrs.push_back(a);
+                    }
+                    uint32_t ti = static_cast<uint32_t>(tris_orig.size());
+                    tris_orig.push_back(tr);
+                    kind_index.push_back((KIND_TRI << 30) | ti);
+                    out.prim_info.push_back(PrimInfo{(KIND_TRI << 30) | ti, ei});
+
+                    PrimRef r{};
+                    r.index = prim;
+                    r.box.grow(v[0]);
+                    r.box.grow(v[1]);
+                    r.box.grow(v[2]);
+                    for(int k = 0; k < 3; ++k) r.centroid[k] = r.box.lo[k] * 0.5f + r.box.hi[k] * 0.5f;
+                    refs.push_back(r);
+
+                    // mesh_surface::get_area(i), :72-76 (double on widened float vertices)
+                    double ax = (double)v[1][0] - v[0][0], ay = (double)v[1][1] - v[0][1], az = (double)v[1][2] - v[0][2];
+                    double bx = (double)v[2][0] - v[0][0], by = (double)v[2][1] - v[0][1], bz = (double)v[2][2] - v[0][2];
+                    double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+                    areas[t] = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+                    area_total += areas[t];
+                }
+                light.kind = KIND_TRI;
+                light.tri_count = ntri;
+                light.inv_area = 1.0 / area_total;
+                if(e.emissive)
+                {
+                    // distribution_1d, distribution.hpp:32-60
+                    light.cdf_offset = static_cast<uint32_t>(out.light_cdf.size());
+                    std::vector<double> cdf(ntri + 1, 0.0);
+                    for(uint32_t t = 1; t <= ntri; ++t) cdf[t] = cdf[t - 1] + areas[t - 1];
+                    double integral = cdf[ntri] / static_cast<double>(ntri);
+                    if(integral != 0.0)
+                    {
+                        for(uint32_t t = 1; t <= ntri; ++t) cdf[t] /= static_cast<double>(ntri) * integral;
+                    }
+                    else
+                    {
+                        for(uint32_t t = 1; t <= ntri; ++t) cdf[t] = static_cast<double>(t) / static_cast<double>(ntri);
+                    }
+                    out.light_cdf.insert(out.light_cdf.end(), cdf.begin(), cdf.end());
+                }
+            }
+            else
+            {
+                err = "unknown surface kind";
+                return FCGPU_E_INVALID;
+            }
+
+            if(e.emissive)
+            {
+                er.light = static_cast<int32_t>(lights.size());
+                lights.push_back(light);
+            }
+            out.entities.push_back(er);
+        }
+        if(kind_index.size() >= (1u << 27))
+        {
+            err = "too many primitives (limit 2^27)";
+            return FCGPU_E_LIMIT;
+        }
+
+        out.light_count = static_cast<uint32_t>(lights.size()) + (d.env_kind != FCGPU_ENV_NONE ? 1u : 0u);
+        out.env_kind = d.env_kind;
+        for(int k = 0; k < 3; ++k)
+        {
+            out.f32.env[k] = static_cast<float>(d.env_color[k]);
+            out.f64.env[k] = d.env_color[k];
+        }
+        if(out.light_cdf.empty()) out.light_cdf.push_back(0.0);
+
+        // ---- BVH: reference-order binary build, then the wide collapse
+        BinaryBvh bin;
+        {
+            BinaryBuilder bb{refs, bin};
+            bin.order.reserve(refs.size());
+            bb.build(0, static_cast<uint32_t>(refs.size()));
+        }
+        out.binary_nodes = static_cast<uint32_t>(bin.nodes.size());
+
+        // triangles re-ordered to leaf order so that leaf ranges read consecutive records
+        std::vector<uint32_t> new_tri_slot(tris_orig.size(), INVALID_U32);
+        for(uint32_t prim : bin.order)
+        {
+            uint32_t ki = kind_index[prim];
+            if((ki >> 30) == KIND_TRI)
+            {
+                uint32_t old = ki & 0x3FFFFFFFu;
+                new_tri_slot[old] = static_cast<uint32_t>(out.tris.size());
+                out.tris.push_back(tris_orig[old]);
+            }
+        }
+        for(size_t p = 0; p < kind_index.size(); ++p)
+        {
+            if((kind_index[p] >> 30) == KIND_TRI)
+            {
+                uint32_t slot = new_tri_slot[kind_index[p] & 0x3FFFFFFFu];
+                kind_index[p] = (KIND_TRI << 30) | slot;
+                out.prim_info[p].kind_index = kind_index[p];
+            }
+        }
+        out.tri_attrs = std::move(attrs);
+        if(out.tris.empty()) out.tris.push_back(TriRec{});
+        if(out.tri_attrs.empty()) out.tri_attrs.push_back(TriAttr{});
+
+        WideBuilder wb{bin, kind_index, out};
+        wb.run();
+        if(out.max_stack > static_cast<uint32_t>(STACK_CAP))
+        {
+            err = "BVH needs a deeper traversal stack than STACK_CAP";
+            return FCGPU_E_LIMIT;
+        }
+
+        convert_xprims(xprims, out.f32.xprims);
+        convert_xprims(xprims, out.f64.xprims);
+        if(out.f32.xprims.empty())
+        {
+            out.f32.xprims.emplace_back();
+            out.f64.xprims.emplace_back();
+        }
+        convert_lights(lights, out.f32.lights);
+        convert_lights(lights, out.f64.lights);
+        if(out.f32.lights.empty())
+        {
+            out.f32.lights.emplace_back();
+            out.f64.lights.emplace_back();
+        }
+        convert_camera(d.camera, out.f32.camera);
+        convert_camera(d.camera, out.f64.camera);
+        return FCGPU_OK;
+    }
+}

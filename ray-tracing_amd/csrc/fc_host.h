@@ -1,0 +1,45 @@
+// fc_host.h -- host-side scene flattening: POD scene description -> device-ready arrays.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/fcgpu.h"
+#include "fc_types.h"
+
+namespace fcg
+{
+    template<typename R>
+    struct FlatTyped  // arrays whose element type depends on the arithmetic type
+    {
+        std::vector<XPrim<R>> xprims;
+        std::vector<LobeRec<R>> lobes;
+        std::vector<MediumRec<R>> media;
+        std::vector<LightRec<R>> lights;
+        CameraRec<R> camera{};
+        R env[3]{};
+    };
+
+    struct FlatScene
+    {
+        std::vector<Node4> nodes;
+        std::vector<uint32_t> leaf_prims;
+        std::vector<TriRec> tris;
+        std::vector<TriAttr> tri_attrs;
+        std::vector<PrimInfo> prim_info;
+        std::vector<EntityRec> entities;
+        std::vector<MaterialRec> materials;
+        std::vector<double> light_cdf;
+        FlatTyped<float> f32;
+        FlatTyped<double> f64;
+        uint32_t light_count{};   // incl. the environment light when present (scene.hpp:66-70)
+        int32_t env_kind{};
+        uint32_t max_stack{};     // worst-case traversal stack depth of the wide BVH
+        uint32_t binary_nodes{};
+        uint32_t lobe_mask{};     // bit t set when some material can pick lobe type t
+        int32_t width{}, height{};
+    };
+
+    // Returns FCGPU_OK or a negative error code with a message in `err`.
+    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err);
+}

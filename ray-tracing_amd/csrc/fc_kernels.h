@@ -1,0 +1,41 @@
+// fc_kernels.h -- host-callable launchers of the wavefront kernels (defined in fc_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "../../include/fcgpu.h"
+#include "fc_types.h"
+
+namespace fcg
+{
+    struct Batch
+    {
+        int32_t x0, y0, tw;          // tile origin and width
+        uint32_t pix0, npix;         // pixel-in-tile range of this batch
+        uint32_t s0, nsamp;          // sample range of this batch; slots = npix * nsamp
+        uint64_t seed;
+        int32_t h;                   // hit index being produced / shaded: 1 = camera ray's hit
+        int32_t max_len;             // max_path_length
+        int32_t integrator;          // FCGPU_INTEGRATOR_*
+        int32_t visible_env;
+        int32_t parity;              // which ray counter extend reads (shade writes parity ^ 1)
+        int32_t W;                   // film width
+        double* film;
+    };
+
+    struct LaunchCfg
+    {
+        hipStream_t stream;
+        int grid;       // persistent grid size (blocks of 256)
+    };
+
+    template<typename R> void launch_generate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);
+    template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);
+    // key in [0, L_COUNT): lobe shade; Q_FINAL: last vertex; Q_MISS: environment term
+    template<typename R> void launch_shade(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key);
+    template<typename R> void launch_shadow(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);
+    template<typename R> void launch_accumulate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);
+    void launch_reset_counters(const LaunchCfg& L, QueueCounters* c, int parity_to_keep);
+
+    template<typename R> void launch_trace(const LaunchCfg& L, const SceneDev<R>& S, uint64_t n, const fcgpu_ray* rays,
+                                           fcgpu_hit* hits, uint8_t* occluded, unsigned long long* stats);
+}

@@ -1,0 +1,831 @@
+// fc_kernels.hip -- the wavefront kernels of the Forward-MIS / Forward-BSDF integrator for gfx950.
+//
+// One sample of forward_mis_integrator::run_once (forward_mis_integrator.hpp:13-210) is cut into
+// stages that each run over a whole queue of paths:
+//
+//   generate   :17-21   camera sample -> first extension ray, path state init
+//   extend     :27,113  helper::raycast = closest hit + priority-medium stack (integrator.hpp:33-109);
+//                       picks the lobe (:48) and files the hit in that lobe's queue (material sort)
+//   shade<L>   :130-147 (arrival: transmittance, emitter + MIS)  then :47-112 (light strategy,
+//                       BSDF sample) for lobe type L; emits one shadow ray and one extension ray
+//   shadow     :84      scene.visibility = any-hit; adds the light-strategy term when unoccluded
+//   accumulate :209     film add with the NaN/Inf guard (perspective_camera.hpp:113-134)
+//
+// Queues are compacted with wave64 ballots + popcount prefix sums, aggregated per 256-thread block
+// through LDS so that a block issues one global atomic per queue.
+// No MFMA: nothing here is a dense contraction.
+#include <hip/hip_runtime.h>
+
+#include "../../include/fcgpu_sampler.h"
+#include "fc_bsdf.h"
+#include "fc_kernels.h"
+#include "fc_traverse.h"
+
+namespace fcg
+{
+    constexpr int BLOCK = 256;
+    constexpr int WAVES = BLOCK / 64;
+
+    // ------------------------------------------------------------------ helpers
+    template<typename R> FC_D void draw(uint64_t key, uint32_t dim, R& x, R& y)
+    {
+        uint64_t bits = fcgpu_sample_bits(key, dim);
+        x = R(fcgpu_sample_x24(bits)) * R(FCGPU_SAMPLER_SCALE);
+        y = R(fcgpu_sample_y24(bits)) * R(FCGPU_SAMPLER_SCALE);
+    }
+
+    FC_D void slot_to_pixel(const Batch& B, uint32_t slot, uint32_t& px, uint32_t& py, uint32_t& sample)
+    {
+        uint32_t sl = slot / B.npix;
+        uint32_t pit = B.pix0 + (slot - sl * B.npix);
+        uint32_t row = pit / static_cast<uint32_t>(B.tw);
+        px = static_cast<uint32_t>(B.x0) + (pit - row * static_cast<uint32_t>(B.tw));
+        py = static_cast<uint32_t>(B.y0) + row;
+        sample = B.s0 + sl;
+    }
+
+    FC_D uint64_t slot_key(const Batch& B, uint32_t slot)
+    {
+        uint32_t px, py, s;
+        slot_to_pixel(B, slot, px, py, s);
+        return fcgpu_sample_key(B.seed, px, py, s);
+    }
+
+    // Block-aggregated multi-queue append. Every thread of the block calls it (uniform control
+    // flow); `key` < NK selects the queue, key < 0 appends nothing. Returns the slot.
+    template<int NK>
+    FC_D uint32_t block_append(int key, uint32_t* const* counters, uint32_t (*lds)[WAVES])
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint64_t lt = (1ull << lane) - 1ull;
+        uint32_t prefix = 0;
+#pragma unroll
+        for(int k = 0; k < NK; ++k)
+        {
+            uint64_t m = __ballot(key == k);
+            if(key == k) prefix = __popcll(m & lt);
+            if(lane == 0) lds[k][wave] = __popcll(m);
+        }
+        __syncthreads();
+        if(threadIdx.x < NK)
+        {
+            uint32_t total = 0;
+#pragma unroll
+            for(int w = 0; w < WAVES; ++w) total += lds[threadIdx.x][w];
+            uint32_t base = total ? atomicAdd(counters[threadIdx.x], total) : 0u;
+#pragma unroll
+            for(int w = 0; w < WAVES; ++w)
+            {
+                uint32_t c = lds[threadIdx.x][w];
+                lds[threadIdx.x][w] = base;
+                base += c;
+            }
+        }
+        __syncthreads();
+        uint32_t slot = key >= 0 ? lds[key][wave] + prefix : INVALID_U32;
+        __syncthreads();
+        return slot;
+    }
+
+    FC_D void wave_stat_add(unsigned long long* stats, int index, uint32_t v)
+    {
+#pragma unroll
+        for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[index], static_cast<unsigned long long>(v));
+    }
+
+    template<typename R> FC_D uint32_t medium_top(const SceneDev<R>& S, uint32_t ms)  // integrator.hpp:51-56
+    {
+        uint32_t top = 0;
+        int top_prio = S.media[0].priority;
+        uint32_t n = ms_count(ms);
+        for(uint32_t i = 0; i < n; ++i)
+        {
+            uint32_t id = ms_get(ms, i);
+            int p = S.media[id].priority;
+            if(p > top_prio)
+            {
+                top_prio = p;
+                top = id;
+            }
+        }
+        return top;
+    }
+
+    FC_D uint32_t medium_push(uint32_t ms, uint32_t id, uint32_t& overflow)  // integrator.hpp:41-42
+    {
+        uint32_t n = ms_count(ms);
+        if(n >= static_cast<uint32_t>(MEDIUM_STACK_CAP))
+        {
+            overflow += 1;
+            return ms;
+        }
+        ms = ms_set(ms, n, id);
+        return (ms & ~7u) | (n + 1);
+    }
+
+    // ------------------------------------------------------------------ generate
+    template<typename R>
+    __global__ __launch_bounds__(BLOCK) void k_generate(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    {
+        const uint32_t n = B.npix * B.nsamp;
+        for(uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        {
+            uint32_t px, py, s;
+            slot_to_pixel(B, i, px, py, s);
+            uint64_t key = fcgpu_sample_key(B.seed, px, py, s);
+            R dx, dy, lx, ly;
+            draw(key, 0u, dx, dy);  // sample_direction
+            draw(key, 1u, lx, ly);  // sample_point (lens)
+            const CameraRec<R>& C = S.camera;
+            // perspective_camera::sample_p_and_wi, perspective_camera.hpp:29-75
+            vec3<R> lens{R(0), R(0), R(0)};
+            if(C.lens_radius != R(0))
+            {
+                R a, b;
+                sample_disk_concentric(lx, ly, a, b);
+                lens.x = a * C.lens_radius;
+                lens.y = b * C.lens_radius;
+            }
+            vec3<R> plane{((R(px) + dx) / R(C.W) - R(0.5)) * C.plane_w, (R(0.5) - (R(py) + dy) / R(C.H)) * C.plane_h, C.focus};
+            vec3<R> dir = plane - lens;
+            vec3<R> wi_l = dir / r_sqrt(dot(dir, dir));
+            vec3<R> wi = xf_dir(C.fwd, wi_l);
+            vec3<R> origin = xf_point(C.fwd, lens);
+            vec3<R> n_cam{C.fwd[2], C.fwd[6], C.fwd[10]};
+            // entity_scene::raycast origin offset, scene.hpp:85-93
+            vec3<R> o = dot(n_cam, wi) > R(0) ? origin + n_cam * S.epsilon : origin - n_cam * S.epsilon;
+
+            PathState<R> st{};
+            st.beta[0] = st.beta[1] = st.beta[2] = R(1);  // beta0 = W*H is folded into the film scale
+            st.flags = 1u;
+            st.p1[0] = origin.x; st.p1[1] = origin.y; st.p1[2] = origin.z;
+            st.w[0] = wi.x; st.w[1] = wi.y; st.w[2] = wi.z;
+            Q.state[i] = st;
+
+            Vec4<R> c0{o.x, o.y, o.z, wi.x};
+            Vec4<R> c1{wi.y, wi.z, R(0), R(0)};
+            pack_ids(c1, i, 0u);
+            Q.ray_c0[i] = c0;
+            Q.ray_c1[i] = c1;
+        }
+        if(blockIdx.x == 0 && threadIdx.x == 0) Q.counters->ray[B.parity] = n;
+    }
+
+    // ------------------------------------------------------------------ extend
+    template<typename R>
+    __global__ __launch_bounds__(BLOCK) void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    {
+        __shared__ uint32_t stack[STACK_CAP * BLOCK];
+        __shared__ uint32_t q_lds[Q_COUNT][WAVES];
+        __shared__ uint32_t* q_ctr[Q_COUNT];
+        if(threadIdx.x < Q_COUNT) q_ctr[threadIdx.x] = &Q.counters->hit[threadIdx.x];
+        __syncthreads();
+
+        const uint32_t n = Q.counters->ray[B.parity];
+        uint32_t n_cast = 0, n_overflow = 0, n_moverflow = 0;
+        const bool last = B.h >= B.max_len;
+        // dimensions per bounce: 6 for forward_mis (fcgpu_sampler.h), 3 for forward_bsdf
+        // (forward_bsdf_integrator.hpp:50,56: lobe pick, then u2, u1)
+        const uint32_t dim_lobe = 2u + (B.integrator == FCGPU_INTEGRATOR_MIS ? 6u : 3u) * static_cast<uint32_t>(B.h - 1);
+
+        for(uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK)
+        {
+            const uint32_t i = base + threadIdx.x;
+            int key = -1;
+            Vec4<R> h0{}, h1{};
+            if(i < n)
+            {
+                Vec4<R> c0 = Q.ray_c0[i], c1 = Q.ray_c1[i];
+                uint32_t path, ms;
+                unpack_ids(c1, path, ms);
+                vec3<R> o{c0.x, c0.y, c0.z}, d{c0.w, c1.x, c1.y};
+                bool alive = false;
+                uint32_t prim = INVALID_U32, entity = 0;
+                vec3<R> p{}, nrm{};
+                R b0 = R(0), b1 = R(0);
+                // helper::raycast, integrator.hpp:33-109 (recursion -> loop)
+                for(int guard = 0; guard < 32; ++guard)
+                {
+                    RayCtx<R> rc = make_ray(o, d);
+                    R t;
+                    uint32_t pk;
+                    n_cast += 1;
+                    if(!traverse<R, false, BLOCK>(S, rc, consts<R>::inf, stack + threadIdx.x, t, pk, b0, b1, n_overflow)) break;
+                    hit_point(S, rc, pk, t, b0, b1, p, nrm, prim, entity);
+                    const uint32_t med = static_cast<uint32_t>(S.entities[entity].medium);
+                    const uint32_t top = medium_top(S, ms);
+                    if(med == 0u)
+                    {
+                        ms = ms_with_media(ms, top, top);
+                        alive = true;
+                        break;
+                    }
+                    const bool entering = dot(d, nrm) <= R(0);
+                    if(entering)
+                    {
+                        if(S.media[med].priority <= S.media[top].priority)
+                        {
+                            ms = medium_push(ms, med, n_moverflow);  // the re-cast leaves p INTO its medium, :36-44
+                            o = p - nrm * S.epsilon;                 // scene.hpp:86-93 with dot(n, w) <= 0
+                            continue;
+                        }
+                        ms = ms_with_media(ms, top, med);
+                        alive = true;
+                        break;
+                    }
+                    uint32_t cnt = ms_count(ms), idx = 0;
+                    for(; idx < cnt; ++idx)
+                        if(ms_get(ms, idx) == med) break;
+                    if(idx == cnt) break;  // leaving a medium never entered: the path dies, :88
+                    ms = ms_set(ms, idx, ms_get(ms, cnt - 1));  // swap with last, :90-91
+                    ms = (ms & ~7u) | (cnt - 1);
+                    const uint32_t new_top = medium_top(S, ms);
+                    if(S.media[new_top].priority == S.media[top].priority)
+                    {
+                        o = p + nrm * S.epsilon;
+                        continue;
+                    }
+                    ms = ms_with_media(ms, new_top, top);
+                    alive = true;
+                    break;
+                }
+                if(alive)
+                {
+                    uint32_t lobe = 0;
+                    if(last)
+                    {
+                        key = Q_FINAL;
+                    }
+                    else
+                    {
+                        // bsdf::sample_bxdf, bsdf.hpp:46-55, on draw `dim_lobe`.x
+                        const MaterialRec m = S.materials[S.entities[entity].material];
+                        uint64_t bits = fcgpu_sample_bits(slot_key(B, path), dim_lobe);
+                        double u = fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
+                        for(int l = m.lobe_count - 1; l >= 0; --l)
+                        {
+                            if(u > S.lobes[m.first_lobe + l].cdf)
+                            {
+                                lobe = static_cast<uint32_t>(l);
+                                break;
+                            }
+                        }
+                        key = S.lobes[m.first_lobe + lobe].type;
+                    }
+                    h0 = Vec4<R>{p.x, p.y, p.z, b0};
+                    h1.x = b1;
+                    h1.y = pack_word(R(0), ms);
+                    pack_ids(h1, prim | (lobe << 30), path);
+                }
+                else if(S.env_kind != FCGPU_ENV_NONE)
+                {
+                    key = Q_MISS;
+                    h1.y = pack_word(R(0), ms);
+                    pack_ids(h1, INVALID_U32, path);
+                }
+            }
+            uint32_t slot = block_append<Q_COUNT>(key, q_ctr, q_lds);
+            if(key >= 0)
+            {
+                Q.hit_c0[key][slot] = h0;
+                Q.hit_c1[key][slot] = h1;
+            }
+        }
+        wave_stat_add(Q.stats, ST_CLOSEST, n_cast);
+        wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow);
+        wave_stat_add(Q.stats, ST_MEDIUM_OVERFLOW, n_moverflow);
+    }
+
+    // ------------------------------------------------------------------ surface point reconstruction
+    template<typename R>
+    struct SurfacePoint
+    {
+        vec3<R> p;
+        ShadingFrame<R> f;
+        uint32_t entity;
+        uint32_t kind_index;
+    };
+
+    template<typename R>
+    FC_D SurfacePoint<R> make_surface_point(const SceneDev<R>& S, uint32_t prim, vec3<R> p, R b0, R b1)
+    {
+        SurfacePoint<R> sp;
+        sp.p = p;
+        const PrimInfo pi = S.prim_info[prim];
+        sp.entity = pi.entity;
+        sp.kind_index = pi.kind_index;
+        const uint32_t kind = pi.kind_index >> 30, idx = pi.kind_index & 0x3FFFFFFFu;
+        if(kind == KIND_TRI)
+        {
+            // mesh_surface.hpp:211-248
+            const TriRec& T = S.tris[idx];
+            vec3<R> p0 = ldv<R>(T.v0), p1 = ldv<R>(T.v1), p2 = ldv<R>(T.v2);
+            vec3<R> dp02 = p0 - p2, dp12 = p1 - p2;
+            sp.f.ng = normalize(cross(dp02, dp12));
+            vec3<R> dpdu;
+            if(T.attr == INVALID_U32)
+            {
+                sp.f.ns = sp.f.ng;
+                // default uvs (0,0),(1,0),(1,1) (:348-351): det = 1, dpdu = dp12 - dp02
+                dpdu = (R(-1) * dp02 - R(-1) * dp12) / R(1);
+            }
+            else
+            {
+                const TriAttr& A = S.tri_attrs[T.attr];
+                R b2 = R(1) - b0 - b1;
+                R d02x = R(A.uv0[0]) - R(A.uv2[0]), d02y = R(A.uv0[1]) - R(A.uv2[1]);
+                R d12x = R(A.uv1[0]) - R(A.uv2[0]), d12y = R(A.uv1[1]) - R(A.uv2[1]);
+                R det = d02x * d12y - d02y * d12x;
+                dpdu = (d12y * dp02 - d02y * dp12) / det;
+                if(S.entities[pi.entity].flags & 1u)
+                    sp.f.ns = normalize(b0 * ldv<R>(A.n0) + b1 * ldv<R>(A.n1) + b2 * ldv<R>(A.n2));
+                else
+                    sp.f.ns = sp.f.ng;
+            }
+            vec3<R> tangent = normalize(dpdu);
+            sp.f.b = cross(tangent, sp.f.ns);
+            sp.f.t = cross(sp.f.ns, sp.f.b);
+        }
+        else
+        {
+            const XPrim<R>& P = S.xprims[idx];
+            if(kind == KIND_SPHERE)
+            {
+                // sphere_surface.hpp:123-140; tangent (-sin phi, 0, cos phi), phi = atan2(z, x), is
+                // (-z, 0, x) / hypot(x, z) -- built from the OBJECT-space position and left unrotated
+                vec3<R> pl = xf_point(P.inv, p);
+                sp.f.ng = xf_dir(P.fwd, normalize(pl));
+                R hyp = r_sqrt(pl.x * pl.x + pl.z * pl.z);
+                vec3<R> tangent = hyp > R(0) ? vec3<R>{-pl.z / hyp, R(0), pl.x / hyp} : vec3<R>{R(0), R(0), R(1)};
+                sp.f.ns = sp.f.ng;
+                sp.f.t = tangent;
+                sp.f.b = cross(tangent, sp.f.ng);
+            }
+            else
+            {
+                // plane_surface.hpp:88-99
+                sp.f.ng = vec3<R>{P.fwd[1], P.fwd[5], P.fwd[9]};
+                sp.f.ns = sp.f.ng;
+                sp.f.t = vec3<R>{P.fwd[0], P.fwd[4], P.fwd[8]};
+                sp.f.b = vec3<R>{P.fwd[2], P.fwd[6], P.fwd[10]};
+            }
+        }
+        return sp;
+    }
+
+    // uniform-area point on an emitter: surface::sample_p
+    template<typename R>
+    FC_D void light_sample_point(const SceneDev<R>& S, const LightRec<R>& Lt, double u_prim, R ux, R uy, vec3<R>& pL, vec3<R>& nL)
+    {
+        if(Lt.kind == KIND_TRI)
+        {
+            // mesh_surface.hpp:276-295 + distribution_1d::sample_discrete, distribution.hpp:94-105
+            const double* cdf = S.light_cdf + Lt.cdf_offset;
+            double u = u_prim;  // already in [0, 1 - 2^-24]
+            uint32_t lo = 0, hi = Lt.tri_count + 1;  // upper_bound over cdf[0..tri_count]
+            while(lo < hi)
+            {
+                uint32_t mid = (lo + hi) >> 1;
+                if(cdf[mid] > u)
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            uint32_t tri = lo - 1;
+            if(tri >= Lt.tri_count) tri = Lt.tri_count - 1;
+            const TriRec& T = S.tris[S.prim_info[Lt.first_prim + tri].kind_index & 0x3FFFFFFFu];
+            vec3<R> p0 = ldv<R>(T.v0), p1 = ldv<R>(T.v1), p2 = ldv<R>(T.v2);
+            R su0 = r_sqrt(ux);  // sample_triangle_uniform, sampling.hpp:62-66
+            R bx = R(1) - su0, by = uy * su0;
+            pL = p0 * bx + p1 * by + p2 * (R(1) - bx - by);
+            nL = normalize(cross(p1 - p0, p2 - p0));
+        }
+        else
+        {
+            const XPrim<R>& P = S.xprims[Lt.index];
+            if(Lt.kind == KIND_SPHERE)
+            {
+                vec3<R> n = sample_sphere_uniform(ux, uy);  // sphere_surface.hpp:157-172
+                pL = xf_point(P.fwd, n * P.a);
+                nL = xf_dir(P.fwd, n);
+            }
+            else
+            {
+                vec3<R> q{(ux - R(0.5)) * P.a, R(0), (uy - R(0.5)) * P.b};  // plane_surface.hpp:116-132
+                pL = xf_point(P.fwd, q);
+                nL = vec3<R>{P.fwd[1], P.fwd[5], P.fwd[9]};
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ shade
+    // KEY in [0, L_COUNT): a path arrives at a hit, then scatters with lobe type KEY.
+    // KEY == Q_FINAL: the last vertex (path length == max_path_length): arrival terms only.
+    template<typename R, int KEY>
+    __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    {
+        __shared__ uint32_t q_lds[2][WAVES];
+        __shared__ uint32_t* q_ctr[2];
+        if(threadIdx.x == 0)
+        {
+            q_ctr[0] = &Q.counters->ray[B.parity ^ 1];
+            q_ctr[1] = &Q.counters->shadow;
+        }
+        __syncthreads();
+
+        const uint32_t n = Q.counters->hit[KEY];
+        const bool mis = B.integrator == FCGPU_INTEGRATOR_MIS;
+        const uint32_t dim = 2u + (mis ? 6u : 3u) * static_cast<uint32_t>(B.h - 1);
+        const uint32_t dim_u2 = dim + (mis ? 4u : 1u), dim_u1 = dim + (mis ? 5u : 2u);
+        const Vec4<R>* hit_c0 = Q.hit_c0[KEY];
+        const Vec4<R>* hit_c1 = Q.hit_c1[KEY];
+
+        for(uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK)
+        {
+            const uint32_t i = base + threadIdx.x;
+            bool emit_ray = false, emit_shadow = false;
+            Vec4<R> r0{}, r1{}, s0{}, s1{}, s2{};
+            if(i < n)
+            {
+                Vec4<R> h0 = hit_c0[i], h1 = hit_c1[i];
+                uint32_t prim_lobe, path;
+                unpack_ids(h1, prim_lobe, path);
+                uint32_t ms = unpack_word(h1.y);
+                PathState<R> st = Q.state[path];
+                vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
+                vec3<R> Li{st.Li[0], st.Li[1], st.Li[2]};
+                const vec3<R> p1{st.p1[0], st.p1[1], st.p1[2]};
+                const vec3<R> w12{st.w[0], st.w[1], st.w[2]};  // direction that reached this hit
+                SurfacePoint<R> sp = make_surface_point(S, prim_lobe & 0x3FFFFFFFu, vec3<R>{h0.x, h0.y, h0.z}, h0.w, h1.x);
+                const EntityRec ent = S.entities[sp.entity];
+                const vec3<R> ng = sp.f.ng;
+                const uint32_t above = ms_above(ms), below = ms_below(ms);
+
+                // ---- arrival at p2 = sp.p along w12 (forward_mis_integrator.hpp:128-147 / :181-196)
+                if(B.h > 1)
+                {
+                    const bool entering = dot(ng, w12) <= R(0);
+                    const MediumRec<R>& M = S.media[entering ? above : below];
+                    R dist = length(sp.p - p1);
+                    beta = beta * vec3<R>{r_exp(-M.sigma[0] * dist), r_exp(-M.sigma[1] * dist), r_exp(-M.sigma[2] * dist)};  // medium.hpp:47-50
+                }
+                if(ent.light >= 0)
+                {
+                    const LightRec<R>& Lt = S.lights[ent.light];
+                    vec3<R> Le = dot(ng, -w12) > R(0) ? rgb(Lt.Le) : vec3<R>{R(0), R(0), R(0)};  // const_diffuse_area_light.hpp:20-26
+                    if((st.flags & 1u) || !mis)
+                    {
+                        Li = Li + beta * Le;  // :40-43, :193-196
+                    }
+                    else
+                    {
+                        R pdf_light = R(1) / R(S.light_count);
+                        R pdf_light_p2 = pdf_light * Lt.inv_area;
+                        vec3<R> d12 = sp.p - p1;
+                        R pdf_bsdf_p2 = st.pdf * r_abs(dot(ng, w12)) / dot(d12, d12);
+                        R weight = power_heuristic(pdf_bsdf_p2, pdf_light_p2);
+                        Li = Li + weight * (beta * Le);  // :140-147
+                    }
+                }
+
+                bool alive = false;
+                R pdf_w12 = R(0);
+                vec3<R> wn{};
+                if constexpr(KEY != Q_FINAL)
+                {
+                    // ---- scatter at p1 := sp.p (forward_mis_integrator.hpp:47-112 / :153-168)
+                    const vec3<R> w10 = -w12;
+                    const MaterialRec mat = S.materials[ent.material];
+                    const LobeRec<R> L = S.lobes[mat.first_lobe + (prim_lobe >> 30)];
+                    const R eta_a = S.media[above].ior, eta_b = S.media[below].ior;
+                    const uint64_t key = slot_key(B, path);
+                    constexpr bool DELTA = KEY == L_SPEC_REFL || KEY == L_SPEC_GLASS || KEY == L_SPEC_TRANS;
+
+                    if(!DELTA && mis && S.light_count > 0u)
+                    {
+                        // light strategy, :52-99
+                        uint64_t bits = fcgpu_sample_bits(key, dim + 1u);
+                        uint32_t li = static_cast<uint32_t>((static_cast<uint64_t>(fcgpu_sample_x24(bits)) * S.light_count) >> 24);
+                        if(li >= S.light_count) li = S.light_count - 1u;  // uniform_light_distribution.hpp:13-17
+                        R pdf_light = R(1) / R(S.light_count);
+                        R ux, uy;
+                        draw(key, dim + 2u, ux, uy);
+                        const bool is_env = S.env_kind != FCGPU_ENV_NONE && li == S.light_count - 1u;
+                        if(is_env)
+                        {
+                            // const_infinity_area_light::sample_wi, const_infinity_area_light.hpp:33-44
+                            vec3<R> env = rgb(S.env);
+                            if(env.x != R(0) || env.y != R(0) || env.z != R(0))
+                            {
+                                vec3<R> wi = sample_sphere_uniform(ux, uy);
+                                R pdf_wi = R(1) / (R(4) * consts<R>::pi);
+                                vec3<R> f = bsdf_evaluate<KEY>(L, sp.f, w10, wi, eta_a, eta_b);
+                                if(f.x != R(0) || f.y != R(0) || f.z != R(0))
+                                {
+                                    R pdf_bsdf = bsdf_pdf_wi<KEY>(L, sp.f, w10, wi, eta_a, eta_b);
+                                    R pdf_l = pdf_light * pdf_wi;
+                                    R weight = power_heuristic(pdf_l, pdf_bsdf);
+                                    vec3<R> c = (beta * f * env) * (weight * r_abs(dot(ng, wi)) / pdf_l);  // :68
+                                    vec3<R> o = dot(ng, wi) > R(0) ? sp.p + ng * S.epsilon : sp.p - ng * S.epsilon;  // scene.hpp:144-157
+                                    emit_shadow = true;
+                                    s0 = Vec4<R>{o.x, o.y, o.z, wi.x};
+                                    s1 = Vec4<R>{wi.y, wi.z, consts<R>::inf, pack_word(R(0), path)};
+                                    s2 = Vec4<R>{c.x, c.y, c.z, R(0)};
+                                }
+                            }
+                        }
+                        else
+                        {
+                            // standard_light::sample_p, const_diffuse_area_light.hpp:28-42
+                            const LightRec<R>& Lt = S.lights[li];
+                            uint64_t pbits = fcgpu_sample_bits(key, dim + 3u);
+                            double u_prim = fcgpu_sample_x24(pbits) * FCGPU_SAMPLER_SCALE;
+                            vec3<R> pL, nL;
+                            light_sample_point(S, Lt, u_prim, ux, uy, pL, nL);
+                            vec3<R> LeL = dot(nL, sp.p - pL) > R(0) ? rgb(Lt.Le) : vec3<R>{R(0), R(0), R(0)};
+                            vec3<R> d1L = pL - sp.p;
+                            vec3<R> w1L = normalize(d1L);
+                            vec3<R> f = bsdf_evaluate<KEY>(L, sp.f, w10, w1L, eta_a, eta_b);
+                            if(f.x != R(0) || f.y != R(0) || f.z != R(0))
+                            {
+                                R x = r_abs(dot(nL, w1L)) / dot(d1L, d1L);
+                                R G = r_abs(dot(ng, w1L)) * x;
+                                R pdf_bsdf_pL = bsdf_pdf_wi<KEY>(L, sp.f, w10, w1L, eta_a, eta_b) * x;
+                                R pdf_light_pL = pdf_light * Lt.inv_area;
+                                R weight = power_heuristic(pdf_light_pL, pdf_bsdf_pL);
+                                vec3<R> c = (beta * f * G * LeL) * (weight / pdf_light_pL);  // :86-91
+                                // entity_scene::visibility(p0, p1), scene.hpp:110-142
+                                vec3<R> q0 = dot(d1L, ng) > R(0) ? sp.p + ng * S.epsilon : sp.p - ng * S.epsilon;
+                                vec3<R> q1 = dot(d1L, nL) < R(0) ? pL + nL * S.epsilon : pL - nL * S.epsilon;
+                                vec3<R> to1 = q1 - q0;
+                                R len = length(to1);
+                                vec3<R> w01 = to1 / len;
+                                emit_shadow = true;
+                                s0 = Vec4<R>{q0.x, q0.y, q0.z, w01.x};
+                                s1 = Vec4<R>{w01.y, w01.z, len, pack_word(R(0), path)};
+                                s2 = Vec4<R>{c.x, c.y, c.z, R(0)};
+                            }
+                        }
+                    }
+
+                    // BSDF strategy, :101-113 / :157-169 (u2 = first draw, u1 = second: right-to-left arguments)
+                    R u1x, u1y, u2x, u2y;
+                    draw(key, dim_u2, u2x, u2y);
+                    draw(key, dim_u1, u1x, u1y);
+                    vec3<R> value;
+                    if(bsdf_sample_wi<KEY>(L, sp.f, w10, eta_a, eta_b, u1x, u1y, u2x, u2y, wn, value, pdf_w12))
+                    {
+                        beta = beta * (value * (r_abs(dot(ng, wn)) / pdf_w12));  // :112
+                        alive = true;
+                        // helper::raycast entry: leaving p into its own medium pushes it, integrator.hpp:36-44
+                        uint32_t overflow = 0;
+                        if(ent.medium != 0 && dot(wn, ng) <= R(0)) ms = medium_push(ms, static_cast<uint32_t>(ent.medium), overflow);
+                        if(overflow) atomicAdd(&Q.stats[ST_MEDIUM_OVERFLOW], 1ull);
+                        vec3<R> o = dot(ng, wn) > R(0) ? sp.p + ng * S.epsilon : sp.p - ng * S.epsilon;
+                        emit_ray = true;
+                        r0 = Vec4<R>{o.x, o.y, o.z, wn.x};
+                        r1 = Vec4<R>{wn.y, wn.z, R(0), R(0)};
+                        pack_ids(r1, path, ms & 0x007FFFFFu);
+                        st.flags = DELTA ? 1u : 0u;
+                    }
+                }
+
+                st.beta[0] = beta.x; st.beta[1] = beta.y; st.beta[2] = beta.z;
+                st.Li[0] = Li.x; st.Li[1] = Li.y; st.Li[2] = Li.z;
+                if(alive)
+                {
+                    st.pdf = pdf_w12;
+                    st.p1[0] = sp.p.x; st.p1[1] = sp.p.y; st.p1[2] = sp.p.z;
+                    st.w[0] = wn.x; st.w[1] = wn.y; st.w[2] = wn.z;
+                }
+                Q.state[path] = st;
+            }
+            if constexpr(KEY != Q_FINAL)
+            {
+                // two independent appends share one pass: queue 0 = extension rays, queue 1 = shadow rays
+                uint32_t slot_r = block_append<1>(emit_ray ? 0 : -1, q_ctr, q_lds);
+                uint32_t slot_s = block_append<1>(emit_shadow ? 0 : -1, q_ctr + 1, q_lds + 1);
+                if(emit_ray)
+                {
+                    Q.ray_c0[slot_r] = r0;
+                    Q.ray_c1[slot_r] = r1;
+                }
+                if(emit_shadow)
+                {
+                    Q.sh_c0[slot_s] = s0;
+                    Q.sh_c1[slot_s] = s1;
+                    Q.sh_c2[slot_s] = s2;
+                }
+            }
+        }
+    }
+
+    // paths that left the scene: environment term (forward_mis_integrator.hpp:29-35, 115-125, 171-178)
+    template<typename R>
+    __global__ __launch_bounds__(BLOCK) void k_miss(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    {
+        const uint32_t n = Q.counters->hit[Q_MISS];
+        const bool mis = B.integrator == FCGPU_INTEGRATOR_MIS;
+        for(uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        {
+            Vec4<R> h1 = Q.hit_c1[Q_MISS][i];
+            uint32_t prim, path;
+            unpack_ids(h1, prim, path);
+            PathState<R>& st = Q.state[path];
+            vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
+            vec3<R> env = rgb(S.env);
+            R weight = R(1);
+            if(B.h == 1)
+            {
+                if(mis && !B.visible_env) weight = R(0);
+            }
+            else if(mis && !(st.flags & 1u))
+            {
+                R pdf_light = R(1) / R(S.light_count);
+                R pdf_light_w12 = pdf_light * (R(1) / (R(4) * consts<R>::pi));
+                weight = power_heuristic(st.pdf, pdf_light_w12);
+            }
+            if(weight != R(0) || weight != weight)
+            {
+                st.Li[0] += weight * beta.x * env.x;
+                st.Li[1] += weight * beta.y * env.y;
+                st.Li[2] += weight * beta.z * env.z;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ shadow
+    template<typename R>
+    __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    {
+        __shared__ uint32_t stack[STACK_CAP * BLOCK];
+        const uint32_t n = Q.counters->shadow;
+        uint32_t n_cast = 0, n_occ = 0, n_overflow = 0;
+        for(uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        {
+            Vec4<R> c0 = Q.sh_c0[i], c1 = Q.sh_c1[i];
+            RayCtx<R> rc = make_ray(vec3<R>{c0.x, c0.y, c0.z}, vec3<R>{c0.w, c1.x, c1.y});
+            R t, b0, b1;
+            uint32_t pk;
+            n_cast += 1;
+            bool occluded = traverse<R, true, BLOCK>(S, rc, c1.z, stack + threadIdx.x, t, pk, b0, b1, n_overflow);
+            if(occluded)
+            {
+                n_occ += 1;
+            }
+            else
+            {
+                Vec4<R> c2 = Q.sh_c2[i];
+                PathState<R>& st = Q.state[unpack_word(c1.w)];
+                st.Li[0] += c2.x;
+                st.Li[1] += c2.y;
+                st.Li[2] += c2.z;
+            }
+        }
+        wave_stat_add(Q.stats, ST_SHADOW, n_cast);
+        wave_stat_add(Q.stats, ST_OCCLUDED, n_occ);
+        wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow);
+    }
+
+    // ------------------------------------------------------------------ accumulate
+    // One thread per pixel of the batch, looping over the batch's samples: one writer per pixel,
+    // so the film sum is deterministic (no float atomics).
+    template<typename R>
+    __global__ __launch_bounds__(BLOCK) void k_accumulate(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    {
+        uint32_t n_nan = 0;
+        for(uint32_t pp = blockIdx.x * BLOCK + threadIdx.x; pp < B.npix; pp += gridDim.x * BLOCK)
+        {
+            uint32_t pit = B.pix0 + pp;
+            uint32_t row = pit / static_cast<uint32_t>(B.tw);
+            uint32_t px = static_cast<uint32_t>(B.x0) + (pit - row * static_cast<uint32_t>(B.tw));
+            uint32_t py = static_cast<uint32_t>(B.y0) + row;
+            double* out = B.film + 3ull * (static_cast<uint64_t>(py) * static_cast<uint64_t>(B.W) + px);
+            double r = out[0], g = out[1], b = out[2];
+            for(uint32_t sl = 0; sl < B.nsamp; ++sl)
+            {
+                const PathState<R>& st = Q.state[sl * B.npix + pp];
+                R x = st.Li[0], y = st.Li[1], z = st.Li[2];
+                if(!r_isfinite(x) || !r_isfinite(y) || !r_isfinite(z))  // perspective_camera.hpp:126-131
+                {
+                    n_nan += 1;
+                    continue;
+                }
+                r += static_cast<double>(x);
+                g += static_cast<double>(y);
+                b += static_cast<double>(z);
+            }
+            out[0] = r;
+            out[1] = g;
+            out[2] = b;
+        }
+        wave_stat_add(Q.stats, ST_NAN, n_nan);
+    }
+
+    __global__ void k_reset_counters(QueueCounters* c, int parity_to_keep)
+    {
+        if(threadIdx.x < Q_COUNT) c->hit[threadIdx.x] = 0;
+        if(threadIdx.x == 0)
+        {
+            c->ray[parity_to_keep ^ 1] = 0;
+            c->shadow = 0;
+        }
+    }
+
+    // ------------------------------------------------------------------ parity hooks
+    template<typename R>
+    __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev<R> S, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits,
+                                                     uint8_t* occluded, unsigned long long* stats)
+    {
+        __shared__ uint32_t stack[STACK_CAP * BLOCK];
+        uint32_t n_overflow = 0;
+        for(uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * BLOCK)
+        {
+            const fcgpu_ray r = rays[i];
+            RayCtx<R> rc = make_ray(vec3<R>{R(r.origin[0]), R(r.origin[1]), R(r.origin[2])},
+                                    vec3<R>{R(r.direction[0]), R(r.direction[1]), R(r.direction[2])});
+            R t, b0, b1;
+            uint32_t pk;
+            if(hits != nullptr)
+            {
+                fcgpu_hit h{};
+                if(traverse<R, false, BLOCK>(S, rc, R(r.t_max), stack + threadIdx.x, t, pk, b0, b1, n_overflow))
+                {
+                    vec3<R> p, nrm;
+                    uint32_t prim, entity;
+                    hit_point(S, rc, pk, t, b0, b1, p, nrm, prim, entity);
+                    h.t = static_cast<double>(t);
+                    h.b0 = static_cast<double>(b0);
+                    h.b1 = static_cast<double>(b1);
+                    h.prim = prim;
+                }
+                else
+                {
+                    h.t = __builtin_huge_val();
+                    h.prim = INVALID_U32;
+                }
+                hits[i] = h;
+            }
+            else
+            {
+                occluded[i] = traverse<R, true, BLOCK>(S, rc, R(r.t_max), stack + threadIdx.x, t, pk, b0, b1, n_overflow) ? 1 : 0;
+            }
+        }
+        wave_stat_add(stats, ST_STACK_OVERFLOW, n_overflow);
+    }
+
+    // ------------------------------------------------------------------ launchers
+    template<typename R> void launch_generate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
+    {
+        hipLaunchKernelGGL(k_generate<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
+    }
+    template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
+    {
+        hipLaunchKernelGGL(k_extend<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
+    }
+    template<typename R> void launch_shade(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key)
+    {
+        dim3 g(L.grid), b(BLOCK);
+        switch(key)
+        {
+        case L_LAMBERT: hipLaunchKernelGGL((k_shade<R, L_LAMBERT>), g, b, 0, L.stream, S, Q, B); break;
+        case L_GGX_REFL: hipLaunchKernelGGL((k_shade<R, L_GGX_REFL>), g, b, 0, L.stream, S, Q, B); break;
+        case L_SPEC_REFL: hipLaunchKernelGGL((k_shade<R, L_SPEC_REFL>), g, b, 0, L.stream, S, Q, B); break;
+        case L_GGX_GLASS: hipLaunchKernelGGL((k_shade<R, L_GGX_GLASS>), g, b, 0, L.stream, S, Q, B); break;
+        case L_SPEC_GLASS: hipLaunchKernelGGL((k_shade<R, L_SPEC_GLASS>), g, b, 0, L.stream, S, Q, B); break;
+        case L_GGX_TRANS: hipLaunchKernelGGL((k_shade<R, L_GGX_TRANS>), g, b, 0, L.stream, S, Q, B); break;
+        case L_SPEC_TRANS: hipLaunchKernelGGL((k_shade<R, L_SPEC_TRANS>), g, b, 0, L.stream, S, Q, B); break;
+        case Q_FINAL: hipLaunchKernelGGL((k_shade<R, Q_FINAL>), g, b, 0, L.stream, S, Q, B); break;
+        case Q_MISS: hipLaunchKernelGGL(k_miss<R>, g, b, 0, L.stream, S, Q, B); break;
+        default: break;
+        }
+    }
+    template<typename R> void launch_shadow(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
+    {
+        hipLaunchKernelGGL(k_shadow<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
+    }
+    template<typename R> void launch_accumulate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
+    {
+        hipLaunchKernelGGL(k_accumulate<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
+    }
+    void launch_reset_counters(const LaunchCfg& L, QueueCounters* c, int parity_to_keep)
+    {
+        hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(64), 0, L.stream, c, parity_to_keep);
+    }
+    template<typename R> void launch_trace(const LaunchCfg& L, const SceneDev<R>& S, uint64_t n, const fcgpu_ray* rays,
+                                           fcgpu_hit* hits, uint8_t* occluded, unsigned long long* stats)
+    {
+        hipLaunchKernelGGL(k_trace<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);
+    }
+
+#define FCG_INSTANTIATE(R)                                                                                             \
+    template void launch_generate<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);          \
+    template void launch_extend<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);            \
+    template void launch_shade<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&, int);        \
+    template void launch_shadow<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);            \
+    template void launch_accumulate<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);        \
+    template void launch_trace<R>(const LaunchCfg&, const SceneDev<R>&, uint64_t, const fcgpu_ray*, fcgpu_hit*, uint8_t*, unsigned long long*);
+    FCG_INSTANTIATE(float)
+    FCG_INSTANTIATE(double)
+}

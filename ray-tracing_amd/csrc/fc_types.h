@@ -1,0 +1,271 @@
+// fc_types.h -- flattened, device-resident scene + wavefront queue layouts (host + device).
+//
+// HBM layout:
+//   nodes      Node4[ ]     64-B 4-wide BVH nodes, child boxes quantised to 8 bit on a
+//                           per-node power-of-two grid, SoA inside the node (x/y/z planes as
+//                           the four bytes of one dword -> v_cvt_f32_ubyte0..3 decode).
+//   leaf_prims u32[ ]       kind(2) | index(30), in BVH leaf order
+//   tris       TriRec[ ]    48-B pre-gathered triangles in BVH leaf order (float vertices, as
+//                           mesh_surface stores them: mesh_surface.hpp:306)
+//   xprims     XPrim<R>[ ]  spheres / planes with their object<->world transforms
+//   queues     SoA columns of Vec4<R>; path state AoS (one cache line per path in fp32)
+#pragma once
+#include <cstdint>
+
+#include "fc_math.h"
+
+namespace fcg
+{
+    constexpr uint32_t INVALID_U32 = 0xFFFFFFFFu;
+
+    // ---- BVH
+    constexpr uint32_t NODE_LEAF_BIT = 0x80000000u;
+    constexpr int MAX_LEAF_PRIMS = 16;
+    constexpr int STACK_CAP = 32;  // LDS traversal stack entries per lane
+
+    struct alignas(16) Node4
+    {
+        float ox, oy, oz;       // grid origin (= node box minimum)
+        uint8_t ex, ey, ez, n;  // biased fp32 exponents of the grid step per axis; n = child count
+        uint32_t qlo[3];        // per axis: byte c = quantised lower bound of child c
+        uint32_t qhi[3];        // per axis: byte c = quantised upper bound of child c
+        uint32_t pad[2];
+        uint32_t child[4];      // interior: node index; leaf: NODE_LEAF_BIT | (count-1)<<27 | first; empty: INVALID_U32
+    };
+    static_assert(sizeof(Node4) == 64, "Node4 must be one 64-byte line");
+
+    FC_HD bool child_is_leaf(uint32_t c) { return (c & NODE_LEAF_BIT) != 0; }
+    FC_HD uint32_t leaf_first(uint32_t c) { return c & 0x07FFFFFFu; }
+    FC_HD uint32_t leaf_count(uint32_t c) { return ((c >> 27) & 0xFu) + 1u; }
+
+    constexpr uint32_t KIND_TRI = 0, KIND_SPHERE = 1, KIND_PLANE = 2;
+
+    struct alignas(16) TriRec
+    {
+        float v0[3]; uint32_t prim;    // global primitive id
+        float v1[3]; uint32_t entity;
+        float v2[3]; uint32_t attr;    // index of vertex attributes (normals/uvs) or INVALID_U32
+    };
+    static_assert(sizeof(TriRec) == 48, "TriRec is 3 x 16 B");
+
+    struct TriAttr  // per-triangle vertex attributes, only for meshes that carry them
+    {
+        float n0[3], n1[3], n2[3];  // world-space vertex normals (mesh_surface.hpp:30-38)
+        float uv0[2], uv1[2], uv2[2];
+        float pad;
+    };
+    static_assert(sizeof(TriAttr) == 64, "TriAttr is one line");
+
+    template<typename R>
+    struct alignas(16) XPrim  // sphere or plane
+    {
+        R inv[12];   // world -> object (pr_transform::inv_t_)
+        R fwd[12];   // object -> world
+        R a, b;      // sphere: a = radius; plane: a = size.x, b = size.y
+        uint32_t prim, entity;
+        R inv_area;
+        R pad;
+    };
+
+    struct PrimInfo  // by global primitive id
+    {
+        uint32_t kind_index;  // kind(2) | index(30) into tris / xprims
+        uint32_t entity;
+    };
+
+    struct EntityRec
+    {
+        int32_t material;
+        int32_t medium;   // 0 = none, else medium id (1-based; medium 0 is the implicit vacuum)
+        int32_t light;    // -1 or light index
+        uint32_t flags;   // bit0 has_normals, bit1 has_uvs
+    };
+
+    // ---- shading
+    enum LobeType : int32_t
+    {
+        L_LAMBERT = 0,     // lambertian_reflection.hpp
+        L_GGX_REFL = 1,    // microfacet_reflection.hpp
+        L_SPEC_REFL = 2,   // specular_reflection.hpp
+        L_GGX_GLASS = 3,   // microfacet_glass.hpp
+        L_SPEC_GLASS = 4,  // specular_glass.hpp
+        L_GGX_TRANS = 5,   // microfacet_transmission.hpp
+        L_SPEC_TRANS = 6,  // specular_transmission.hpp
+        L_COUNT = 7
+    };
+    // wavefront queue keys: one hit queue per lobe type + the last-vertex queue + the miss queue
+    constexpr int Q_FINAL = L_COUNT;
+    constexpr int Q_MISS = L_COUNT + 1;
+    constexpr int Q_COUNT = L_COUNT + 2;
+
+    FC_HD bool lobe_is_delta(int t) { return t == L_SPEC_REFL || t == L_SPEC_GLASS || t == L_SPEC_TRANS; }
+
+    template<typename R>
+    struct LobeRec
+    {
+        int32_t type;
+        int32_t fresnel;   // 0 = fresnel_one, 1 = fresnel_dielectric (microfacet_reflection.hpp:18-35)
+        R color[3];        // reflectance (or transmittance for the *_TRANS lobes)
+        R color2[3];       // transmittance of the glass lobes
+        R alpha[2];        // max(roughness, 0.002)^2, microfacet.hpp:76-81
+        R ior;             // material ior used by the reflection lobes' Fresnel
+        R factor;          // bsdf scale / lobe pick pdf (bsdf.hpp:70,96)
+        double cdf;        // exclusive prefix of the pick pdfs (bsdf.hpp:39-43), compared in double
+    };
+
+    struct MaterialRec
+    {
+        int32_t first_lobe;
+        int32_t lobe_count;
+    };
+
+    constexpr int MAX_MEDIA = 15;       // 4-bit medium ids, 0 = vacuum
+    constexpr int MEDIUM_STACK_CAP = 5; // nested media beyond the vacuum (reference: 9, integrator.hpp:24)
+
+    template<typename R>
+    struct MediumRec
+    {
+        int32_t priority;
+        int32_t pad;
+        R ior;
+        R sigma[3];  // colour * density (medium.hpp:49)
+    };
+
+    template<typename R>
+    struct LightRec
+    {
+        int32_t entity;
+        uint32_t kind;        // KIND_TRI (mesh) / KIND_SPHERE / KIND_PLANE
+        uint32_t index;       // xprims index (sphere / plane)
+        uint32_t first_prim;  // mesh: global id of its first triangle
+        uint32_t tri_count;
+        uint32_t cdf_offset;  // mesh: offset into light_cdf (tri_count + 1 doubles)
+        R Le[3];
+        R inv_area;           // pdf_p = 1 / area (mesh_surface.hpp:292, sphere :170, plane :129)
+    };
+
+    template<typename R>
+    struct CameraRec
+    {
+        R fwd[12];
+        R plane_w, plane_h;   // sample_plane_size_ (perspective_camera.hpp:24-26)
+        R focus, lens_radius;
+        int32_t W, H;
+    };
+
+    template<typename R>
+    struct SceneDev
+    {
+        const Node4* nodes;
+        const uint32_t* leaf_prims;
+        const TriRec* tris;
+        const TriAttr* tri_attrs;
+        const XPrim<R>* xprims;
+        const PrimInfo* prim_info;
+        const EntityRec* entities;
+        const MaterialRec* materials;
+        const LobeRec<R>* lobes;
+        const MediumRec<R>* media;
+        const LightRec<R>* lights;
+        const double* light_cdf;
+        CameraRec<R> camera;
+        uint32_t light_count;
+        int32_t env_kind;
+        R env[3];
+        R epsilon;
+    };
+
+    // ---- wavefront queues
+    template<typename R>
+    struct alignas(16) Vec4
+    {
+        R x, y, z, w;
+    };
+
+    // two 32-bit ids travel in the tail of an R column: two float slots or one double slot
+    FC_HD void pack_ids(Vec4<float>& v, uint32_t a, uint32_t b)
+    {
+        v.z = __builtin_bit_cast(float, a);
+        v.w = __builtin_bit_cast(float, b);
+    }
+    FC_HD void unpack_ids(const Vec4<float>& v, uint32_t& a, uint32_t& b)
+    {
+        a = __builtin_bit_cast(uint32_t, v.z);
+        b = __builtin_bit_cast(uint32_t, v.w);
+    }
+    FC_HD void pack_ids(Vec4<double>& v, uint32_t a, uint32_t b)
+    {
+        v.z = __builtin_bit_cast(double, (static_cast<uint64_t>(a) << 32) | b);
+        v.w = 0.0;
+    }
+    FC_HD void unpack_ids(const Vec4<double>& v, uint32_t& a, uint32_t& b)
+    {
+        uint64_t u = __builtin_bit_cast(uint64_t, v.z);
+        a = static_cast<uint32_t>(u >> 32);
+        b = static_cast<uint32_t>(u);
+    }
+
+    // one 32-bit word in a single R slot
+    FC_HD float pack_word(float, uint32_t a) { return __builtin_bit_cast(float, a); }
+    FC_HD double pack_word(double, uint32_t a) { return __builtin_bit_cast(double, static_cast<uint64_t>(a)); }
+    FC_HD uint32_t unpack_word(float v) { return __builtin_bit_cast(uint32_t, v); }
+    FC_HD uint32_t unpack_word(double v) { return static_cast<uint32_t>(__builtin_bit_cast(uint64_t, v)); }
+
+    // medium stack word: count(3) | 5 x id(4) | above(4) | below(4)
+    FC_HD uint32_t ms_count(uint32_t m) { return m & 7u; }
+    FC_HD uint32_t ms_get(uint32_t m, uint32_t i) { return (m >> (3 + 4 * i)) & 15u; }
+    FC_HD uint32_t ms_set(uint32_t m, uint32_t i, uint32_t id) { return (m & ~(15u << (3 + 4 * i))) | (id << (3 + 4 * i)); }
+    FC_HD uint32_t ms_above(uint32_t m) { return (m >> 23) & 15u; }
+    FC_HD uint32_t ms_below(uint32_t m) { return (m >> 27) & 15u; }
+    FC_HD uint32_t ms_with_media(uint32_t m, uint32_t above, uint32_t below)
+    {
+        return (m & 0x007FFFFFu) | (above << 23) | (below << 27);
+    }
+
+    // per-path persistent state, AoS: 64 B in fp32 (one line), 128 B in fp64
+    template<typename R>
+    struct alignas(16) PathState
+    {
+        R beta[3];
+        R pdf;        // pdf_w12 of the last BSDF sample (forward_mis_integrator.hpp:104)
+        R Li[3];
+        uint32_t flags;  // bit0: last lobe was delta (or camera segment): emitter hits un-weighted
+        uint32_t pad0;
+        R p1[3];      // previous vertex (un-offset), for transmittance and the area-measure pdf
+        R pad1;
+        R w[3];       // direction of the segment that produced the current hit (w12)
+        R pad2;
+    };
+
+    struct QueueCounters  // device-resident, zeroed per bounce
+    {
+        uint32_t hit[Q_COUNT];
+        uint32_t ray[2];     // ping-pong: extension rays of this / the next bounce
+        uint32_t shadow;
+        uint32_t pad[4];
+    };
+
+    enum StatIndex
+    {
+        ST_CLOSEST = 0, ST_SHADOW = 1, ST_OCCLUDED = 2, ST_NAN = 3, ST_STACK_OVERFLOW = 4, ST_MEDIUM_OVERFLOW = 5, ST_COUNT = 8
+    };
+
+    template<typename R>
+    struct Wavefront
+    {
+        // extension rays: c0 = {o.xyz, d.x}, c1 = {d.y, d.z, ids(path, mstack)}
+        Vec4<R>* ray_c0;
+        Vec4<R>* ray_c1;
+        // hits per key: c0 = {p.xyz, b0}, c1 = {b1, word(mstack), ids(prim|lobe<<30, path)}
+        Vec4<R>* hit_c0[Q_COUNT];
+        Vec4<R>* hit_c1[Q_COUNT];
+        // shadow rays: c0 = {o.xyz, d.x}, c1 = {d.y, d.z, tmax, path}, c2 = {contribution rgb, -}
+        Vec4<R>* sh_c0;
+        Vec4<R>* sh_c1;
+        Vec4<R>* sh_c2;
+        PathState<R>* state;
+        QueueCounters* counters;
+        unsigned long long* stats;
+        uint32_t capacity;
+    };
+}
