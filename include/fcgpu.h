@@ -184,6 +184,20 @@ typedef struct fcgpu_counters {
     uint64_t reserved[7];
 } fcgpu_counters;
 
+/* per-stage device time, measured with HIP events on the context's stream around each launch
+ * group while profiling is enabled (bench.py's roofline leg). No counterpart in the reference
+ * (it has no profiling). */
+#define FCGPU_STAGE_GENERATE 0
+#define FCGPU_STAGE_EXTEND 1
+#define FCGPU_STAGE_SHADE 2
+#define FCGPU_STAGE_SHADOW 3
+#define FCGPU_STAGE_ACCUMULATE 4
+#define FCGPU_STAGE_COUNT 8
+typedef struct fcgpu_stage_times {
+    double ms[FCGPU_STAGE_COUNT];        /* summed device milliseconds per stage */
+    uint64_t launches[FCGPU_STAGE_COUNT];/* timed launch groups per stage */
+} fcgpu_stage_times;
+
 typedef struct fcgpu_ctx fcgpu_ctx;
 
 /* ------------------------------------------------------------------ entry points */
@@ -238,6 +252,10 @@ int fcgpu_add_sample_count(fcgpu_ctx* ctx, int64_t delta);
 int fcgpu_get_counters(fcgpu_ctx* ctx, fcgpu_counters* out);
 int fcgpu_reset_counters(fcgpu_ctx* ctx);
 int fcgpu_sync(fcgpu_ctx* ctx);
+/* Stage timing (see fcgpu_stage_times). fcgpu_get_stage_times synchronises, then returns and
+ * clears the sums accumulated since the previous call.                                       */
+int fcgpu_set_profiling(fcgpu_ctx* ctx, int enabled);
+int fcgpu_get_stage_times(fcgpu_ctx* ctx, fcgpu_stage_times* out);
 /* HIP stream the context launches on (hipStream_t as void*), so callers can bracket launches
  * with their own events.                                                                     */
 int fcgpu_stream(fcgpu_ctx* ctx, void** stream);

@@ -51,17 +51,18 @@ def _load(path, prefix):
 class _Backend:
     """Common driver for the two CPU checkers (same C entry points, different prefix)."""
 
-    def __init__(self, path, prefix):
+    def __init__(self, path, prefix, default_epsilon=None):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.lib = _load(path, prefix)
         self.prefix = prefix
+        self.default_epsilon = default_epsilon
 
     def _fn(self, name):
         return getattr(self.lib, self.prefix + name)
 
-    def scene(self, scene):
-        return _Scene(self, scene)
+    def scene(self, scene, epsilon=None):
+        return _Scene(self, scene, epsilon)
 
     def bsdf_table(self, material, queries, ng=(0, 1, 0), tangent=(1, 0, 0), ns=(0, 1, 0), bitangent=(0, 0, 1),
                    eta_a=1.0, eta_b=1.0):
@@ -76,13 +77,21 @@ class _Backend:
 
 
 class _Scene:
-    def __init__(self, backend, scene):
+    def __init__(self, backend, scene, epsilon=None):
         self.b = backend
         self.scene = scene
         self.desc = scene.desc()
         self.h = backend._fn("_scene_create")(C.byref(self.desc))
         if not self.h:
             raise RuntimeError("scene_create failed")
+        if epsilon is None:
+            epsilon = backend.default_epsilon
+        if epsilon is not None:
+            # ray-origin offset (scene.hpp:182 fixes 1e-6; an fp32 build needs the device's fp32-safe 1e-4)
+            f = backend._fn("_set_epsilon")
+            f.argtypes = [C.c_void_p, C.c_double]
+            f.restype = None
+            f(self.h, float(epsilon))
         self.width, self.height = scene.camera.width, scene.camera.height
 
     def close(self):
@@ -141,7 +150,7 @@ def have_reference():
 
 def restatement(precision="f64"):
     """The independent CPU restatement (oracle/liboracle.so); precision 'f64' or 'f32'."""
-    return _Backend(os.path.join(_HERE, "liboracle.so"), "fcoracle_" + precision)
+    return _Backend(os.path.join(_HERE, "liboracle.so"), "fcoracle_" + precision, 1e-4 if precision == "f32" else 1e-6)
 
 
 def image_from_film(rgb_sum, count):

@@ -98,6 +98,12 @@ class Counters(C.Structure):
     ]
 
 
+class StageTimes(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
+
+
+STAGE_NAMES = ["generate", "extend", "shade", "shadow", "accumulate"]
+
 # numpy dtypes with the same layout as Ray / Hit (for bulk ray sets)
 import numpy as _np
 
@@ -111,5 +117,5 @@ EXPORTS = [
     "fcgpu_set_sampler", "fcgpu_render_pass", "fcgpu_trace_closest", "fcgpu_trace_any",
     "fcgpu_trace_closest_device", "fcgpu_trace_any_device", "fcgpu_clear_film", "fcgpu_read_film",
     "fcgpu_film_device_ptr", "fcgpu_add_sample_count", "fcgpu_get_counters", "fcgpu_reset_counters",
-    "fcgpu_sync", "fcgpu_stream", "fcgpu_export_image", "fcgpu_version",
+    "fcgpu_sync", "fcgpu_set_profiling", "fcgpu_get_stage_times", "fcgpu_stream", "fcgpu_export_image", "fcgpu_version",
 ]

@@ -52,6 +52,15 @@ struct fcgpu_ctx
     uint64_t samples{};
     uint64_t launches{};
     int grid{};
+    // stage profiling: a pool of event pairs drained at sync points
+    bool profiling{};
+    struct TimedSpan
+    {
+        hipEvent_t a, b;
+        int stage;
+    };
+    std::vector<TimedSpan> spans_free, spans_busy;
+    fcgpu_stage_times stage_times{};
 };
 
 namespace
@@ -104,6 +113,53 @@ namespace
         S.env_kind = c->flat.env_kind;
         return FCGPU_OK;
     }
+
+    void drain_spans(fcgpu_ctx* c)
+    {
+        if(c->spans_busy.empty()) return;
+        (void)hipStreamSynchronize(c->stream);
+        for(auto& s : c->spans_busy)
+        {
+            float ms = 0.0f;
+            if(hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess)
+            {
+                c->stage_times.ms[s.stage] += ms;
+                c->stage_times.launches[s.stage] += 1;
+            }
+            c->spans_free.push_back(s);
+        }
+        c->spans_busy.clear();
+    }
+
+    // RAII span: records an event pair around the launches issued during its lifetime
+    struct StageSpan
+    {
+        fcgpu_ctx* c;
+        fcgpu_ctx::TimedSpan s{};
+        bool on{};
+        StageSpan(fcgpu_ctx* ctx, int stage) : c{ctx}
+        {
+            if(!c->profiling) return;
+            if(c->spans_busy.size() >= 8192) drain_spans(c);
+            if(!c->spans_free.empty())
+            {
+                s = c->spans_free.back();
+                c->spans_free.pop_back();
+            }
+            else if(hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess)
+            {
+                return;
+            }
+            s.stage = stage;
+            on = hipEventRecord(s.a, c->stream) == hipSuccess;
+        }
+        ~StageSpan()
+        {
+            if(!on) return;
+            (void)hipEventRecord(s.b, c->stream);
+            c->spans_busy.push_back(s);
+        }
+    };
 
     double effective_epsilon(const fcgpu_ctx* c)
     {
@@ -189,8 +245,11 @@ namespace
             B.nsamp = nsamp;
             B.parity = 0;
             B.h = 1;
-            launch_reset_counters(L, c->counters, 0);
-            launch_generate(L, S, Q, B);
+            {
+                StageSpan sp{c, FCGPU_STAGE_GENERATE};
+                launch_reset_counters(L, c->counters, 0);
+                launch_generate(L, S, Q, B);
+            }
             c->launches += 2;
             for(int h = 1; h <= max_len; ++h)
             {
@@ -200,37 +259,47 @@ namespace
                     launch_reset_counters(L, c->counters, B.parity);
                     c->launches += 1;
                 }
-                launch_extend(L, S, Q, B);
-                c->launches += 1;
-                if(h < max_len)
                 {
-                    for(int k = 0; k < L_COUNT; ++k)
+                    StageSpan sp{c, FCGPU_STAGE_EXTEND};
+                    launch_extend(L, S, Q, B);
+                }
+                c->launches += 1;
+                {
+                    StageSpan sp{c, FCGPU_STAGE_SHADE};
+                    if(h < max_len)
                     {
-                        if(c->flat.lobe_mask >> k & 1u)
+                        for(int k = 0; k < L_COUNT; ++k)
                         {
-                            launch_shade(L, S, Q, B, k);
-                            c->launches += 1;
+                            if(c->flat.lobe_mask >> k & 1u)
+                            {
+                                launch_shade(L, S, Q, B, k);
+                                c->launches += 1;
+                            }
                         }
                     }
-                }
-                else
-                {
-                    launch_shade(L, S, Q, B, Q_FINAL);
-                    c->launches += 1;
-                }
-                if(c->flat.env_kind != FCGPU_ENV_NONE)
-                {
-                    launch_shade(L, S, Q, B, Q_MISS);
-                    c->launches += 1;
+                    else
+                    {
+                        launch_shade(L, S, Q, B, Q_FINAL);
+                        c->launches += 1;
+                    }
+                    if(c->flat.env_kind != FCGPU_ENV_NONE)
+                    {
+                        launch_shade(L, S, Q, B, Q_MISS);
+                        c->launches += 1;
+                    }
                 }
                 if(h < max_len && integrator == FCGPU_INTEGRATOR_MIS)
                 {
+                    StageSpan sp{c, FCGPU_STAGE_SHADOW};
                     launch_shadow(L, S, Q, B);
                     c->launches += 1;
                 }
                 B.parity ^= 1;
             }
-            launch_accumulate(L, S, Q, B);
+            {
+                StageSpan sp{c, FCGPU_STAGE_ACCUMULATE};
+                launch_accumulate(L, S, Q, B);
+            }
             c->launches += 1;
         };
 
@@ -361,6 +430,12 @@ extern "C"
         if(!c) return FCGPU_E_INVALID;
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        drain_spans(c);
+        for(auto& s : c->spans_free)
+        {
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
         free_pool(c->scene_allocs);
         free_pool(c->queue_allocs);
         if(c->film) (void)hipFree(c->film);
@@ -561,6 +636,25 @@ extern "C"
         if(!c) return FCGPU_E_INVALID;
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return FCGPU_OK;
+    }
+
+    int fcgpu_set_profiling(fcgpu_ctx* c, int enabled)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        HIP_TRY(c, hipSetDevice(c->device));
+        drain_spans(c);
+        c->profiling = enabled != 0;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_get_stage_times(fcgpu_ctx* c, fcgpu_stage_times* out)
+    {
+        if(!c || !out) return fail(c, FCGPU_E_INVALID, "null argument");
+        HIP_TRY(c, hipSetDevice(c->device));
+        drain_spans(c);
+        *out = c->stage_times;
+        c->stage_times = fcgpu_stage_times{};
         return FCGPU_OK;
     }
 

@@ -53,6 +53,8 @@ def load_library():
         "fcgpu_get_counters": (i32, [vp, P(A.Counters)]),
         "fcgpu_reset_counters": (i32, [vp]),
         "fcgpu_sync": (i32, [vp]),
+        "fcgpu_set_profiling": (i32, [vp, i32]),
+        "fcgpu_get_stage_times": (i32, [vp, P(A.StageTimes)]),
         "fcgpu_stream": (i32, [vp, P(vp)]),
         "fcgpu_export_image": (i32, [vp, C.c_char_p]),
         "fcgpu_version": (i32, []),
@@ -176,6 +178,15 @@ class GpuContext:
 
     def sync(self):
         self._check(self.lib.fcgpu_sync(self.h))
+
+    def set_profiling(self, enabled):
+        self._check(self.lib.fcgpu_set_profiling(self.h, int(enabled)))
+
+    def stage_times(self):
+        """{stage: (device ms, timed launch groups)} since the previous call (HIP events on the stream)."""
+        t = A.StageTimes()
+        self._check(self.lib.fcgpu_get_stage_times(self.h, C.byref(t)))
+        return {n: (t.ms[i], t.launches[i]) for i, n in enumerate(A.STAGE_NAMES)}
 
     def stream(self):
         s = C.c_void_p()

@@ -1,0 +1,33 @@
+"""Shared helpers for the test suite."""
+import ast
+import importlib
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+S = importlib.import_module("ray-tracing_amd.scenes")
+A = importlib.import_module("ray-tracing_amd._abi")
+R = importlib.import_module("ray-tracing_amd.renderer")
+
+FILM_FIXTURES = sorted(f[5:-4] for f in os.listdir(GOLDEN) if f.startswith("film_"))
+RAY_FIXTURES = sorted(f[5:-4] for f in os.listdir(GOLDEN) if f.startswith("rays_"))
+
+
+def load_film(name):
+    z = np.load(os.path.join(GOLDEN, f"film_{name}.npz"))
+    scene = S.BUILDERS[str(z["builder"])](**ast.literal_eval(str(z["kwargs"])))
+    return z, scene
+
+
+def load_rays(name):
+    z = np.load(os.path.join(GOLDEN, f"rays_{name}.npz"))
+    scene = S.BUILDERS[str(z["builder"])](**ast.literal_eval(str(z["kwargs"])))
+    return z, scene
+
+
+def pixel_rel_err(img, ref):
+    """per-pixel max-channel error relative to the reference pixel (floored at 1e-3 of the image mean)"""
+    floor = 1e-3 * max(float(np.abs(ref).mean()), 1e-30)
+    return np.abs(img - ref).max(axis=2) / np.maximum(np.abs(ref).max(axis=2), floor)

@@ -1,0 +1,133 @@
+"""Size-independent properties of the GPU path at larger sizes, and the C-ABI's error behaviour."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import A, R, S
+
+pytestmark = pytest.mark.gpu
+
+
+def render(scene, precision="f32", spp=2, seed=0, tiles=None, cap=0, begin=0, integrator=A.INTEGRATOR_MIS):
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision=precision, max_paths_in_flight=cap)
+        ctx.upload_scene(scene)
+        ctx.set_sampler(seed)
+        for t in (tiles or [None]):
+            ctx.render_pass(begin, spp, integrator, 10, True, t)
+        rgb, n = ctx.read_film()
+        c = ctx.counters()
+    assert c.stack_overflows == 0
+    return rgb, n, c
+
+
+def test_deterministic_and_batching_invariant():
+    sc = S.room(width=320, height=180, tess=16)
+    a, n, _ = render(sc, spp=3)
+    b, m, _ = render(sc, spp=3)
+    assert n == m and np.array_equal(a, b)  # no float atomics anywhere: bitwise reproducible
+    c, _, _ = render(sc, spp=3, cap=4096)   # many small batches (pixel ranges of one sample)
+    assert np.array_equal(a, c)
+    d, _, _ = render(sc, spp=3, cap=1 << 18)  # several samples per batch
+    assert np.array_equal(a, d)
+
+
+def test_tile_sharding_is_bit_exact():
+    sc = S.room(width=256, height=144, tess=8)
+    full, n, _ = render(sc, spp=2)
+    acc = np.zeros_like(full)
+    cnt = 0
+    for rank in range(4):
+        part, k, _ = render(sc, spp=2, tiles=R.shard_tiles(256, 144, rank, 4, 32))
+        acc += part
+        cnt += k
+    assert cnt == n and np.array_equal(acc, full)
+
+
+def test_sample_pass_split_sums():
+    sc = S.room(width=128, height=72, tess=8)
+    full, n, _ = render(sc, spp=4, precision="f64")
+    a, n1, _ = render(sc, spp=2, begin=0, precision="f64")
+    b, n2, _ = render(sc, spp=2, begin=2, precision="f64")
+    assert n1 + n2 == n
+    assert np.allclose(a + b, full, rtol=1e-13, atol=0)
+
+
+def test_emission_linearity():
+    """Scaling every emitter by 2 scales the image by exactly 2 (power of two: exact in fp)."""
+    sc1 = S.room(width=96, height=54, tess=4)
+    sc2 = S.room(width=96, height=54, tess=4)
+    for e in sc2.entities:
+        e.emission_strength *= 2.0
+    a, _, _ = render(sc1, spp=2)
+    b, _, _ = render(sc2, spp=2)
+    assert np.array_equal(2.0 * a, b)
+
+
+def test_tessellation_invariance():
+    """Flat tessellation of the walls does not change the image beyond fp32 noise."""
+    a, _, _ = render(S.room(width=96, height=54, tess=2), spp=4, precision="f64")
+    b, _, _ = render(S.room(width=96, height=54, tess=32), spp=4, precision="f64")
+    rel = np.abs(a - b).max(axis=2) / np.maximum(a.max(axis=2), 1e-3 * a.mean())
+    assert (rel <= 1e-6).mean() >= 0.97  # vertices of finer grids are rounded to float at other places
+
+
+def test_bsdf_and_mis_agree_in_expectation():
+    sc = S.room(width=64, height=36, tess=4)
+    a, n, _ = render(sc, spp=256, integrator=A.INTEGRATOR_MIS)
+    b, m, _ = render(sc, spp=256, integrator=A.INTEGRATOR_BSDF)
+    assert abs(a.mean() / n - b.mean() / m) <= 0.05 * (a.mean() / n)
+
+
+def test_full_size_pass_counters():
+    """One sample of the headline frame: every path traced, ray budget as the survey measured."""
+    sc = S.room(width=1920, height=1080, tess=64)
+    rgb, n, c = render(sc, spp=1)
+    assert n == 1920 * 1080
+    rays = (c.closest_rays + c.shadow_rays) / n
+    assert 17.5 <= rays <= 19.5  # 18.47 rays / sample
+    assert np.isfinite(rgb).all() and rgb.min() >= 0 and c.nan_samples == 0
+
+
+def test_error_codes():
+    lib = R.load_library()
+    ctx = R.GpuContext(0)
+    with pytest.raises(R.FcgpuError) as e:
+        ctx.render_pass(0, 1)
+    assert e.value.code == A.E_NOSCENE
+    sc = S.room_planes(32, 18)
+    ctx.upload_scene(sc)
+    with pytest.raises(R.FcgpuError) as e:
+        ctx.render_pass(0, 1, tile=(0, 0, 64, 64))
+    assert e.value.code == A.E_INVALID
+    with pytest.raises(R.FcgpuError) as e:
+        ctx.render_pass(0, 1, integrator=7)
+    assert e.value.code == A.E_INVALID
+    bad = S.room_planes(32, 18)
+    bad.entities[0].material = 99
+    with pytest.raises(R.FcgpuError) as e:
+        ctx.upload_scene(bad)
+    assert e.value.code == A.E_INVALID
+    assert b"entity" in lib.fcgpu_last_error(ctx.h)
+    h = C.c_void_p()
+    assert lib.fcgpu_create(4096, C.byref(h)) == A.E_INVALID
+    ctx.close()
+
+
+def test_empty_and_degenerate_inputs():
+    sc = S.room_planes(16, 9)
+    with R.GpuContext(0) as ctx:
+        ctx.upload_scene(sc)
+        assert len(ctx.trace_closest(np.zeros(0, dtype=A.ray_dtype))) == 0
+        ctx.render_pass(0, 0)  # zero samples: a no-op
+        rgb, n = ctx.read_film()
+        assert n == 0 and rgb.max() == 0
+        rays = np.zeros(3, dtype=A.ray_dtype)
+        rays["origin"] = [[0, 4, 5], [0, 4, 5], [0, 100, 5]]
+        rays["direction"] = [[0, 1, 0], [0, 0, 1], [0, 1, 0]]  # axis-parallel rays
+        rays["t_max"] = [np.inf, 1.0, np.inf]
+        hits = ctx.trace_closest(rays)
+        assert hits["prim"][0] == 6 and abs(hits["t"][0] - 3.9) < 1e-5  # the plane emitter at y = 7.9
+        assert hits["prim"][1] == 0xFFFFFFFF  # t_max shorter than the wall distance
+        assert hits["prim"][2] == 0xFFFFFFFF  # outside the room, pointing away

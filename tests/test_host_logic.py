@@ -1,0 +1,61 @@
+"""Host-side logic that needs no GPU: scene descriptions, tile sharding, sampler statistics."""
+import numpy as np
+
+from common import A, R, S
+from oracle import pyref
+
+
+def test_room_primitive_counts():
+    sc = S.room(width=64, height=36, tess=4)
+    counts = sc.primitive_counts()
+    assert counts[0] == 12 * 4 * 4 and counts[1] == 8 * 10 and counts[2] == 8 * 2 and counts[3:] == [1, 1, 1]
+    d = sc.desc()
+    assert d.entity_count == 6 and d.medium_count == 1 and d.index_total == 3 * sum(counts[:3])
+
+
+def test_shard_tiles_partition_every_pixel_once():
+    for (w, h, world, tile) in ((1920, 1080, 8, 64), (7680, 4320, 8, 128), (100, 37, 3, 16), (64, 64, 2, 64)):
+        cover = np.zeros((h, w), np.int32)
+        sizes = []
+        for rank in range(world):
+            tiles = R.shard_tiles(w, h, rank, world, tile)
+            sizes.append(sum(t[2] * t[3] for t in tiles))
+            for x0, y0, tw, th in tiles:
+                cover[y0:y0 + th, x0:x0 + tw] += 1
+        assert cover.min() == 1 and cover.max() == 1
+        if w * h > 100000:
+            assert max(sizes) <= 1.15 * (w * h / world)  # balanced within 15 %
+
+
+def test_sampler_is_uniform_and_decorrelated():
+    # draws of the oracle build of fcgpu_sampler.h through a 1-lobe table query would be indirect;
+    # re-implement the integer mixing with numpy uint64 (wraps mod 2^64) and test statistics
+    def mix64(z):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+    with np.errstate(over="ignore"):
+        px = np.arange(256, dtype=np.uint64)[:, None]
+        s = np.arange(256, dtype=np.uint64)[None, :]
+        key = mix64(mix64(px | (np.uint64(3) << np.uint64(20)) | (s << np.uint64(40))) ^ np.uint64(0xD1B54A32D192ED03))
+        bits = mix64(key + np.uint64(1) * np.uint64(0x9E3779B97F4A7C15))
+    x = (bits >> np.uint64(40)).astype(np.float64) / 2 ** 24
+    y = ((bits & np.uint64(0xFFFFFFFF)) >> np.uint64(8)).astype(np.float64) / 2 ** 24
+    assert abs(x.mean() - 0.5) < 0.005 and abs(y.mean() - 0.5) < 0.005
+    assert abs(np.corrcoef(x.ravel(), y.ravel())[0, 1]) < 0.02
+    assert abs(np.corrcoef(x[:, :-1].ravel(), x[:, 1:].ravel())[0, 1]) < 0.02
+    hist, _ = np.histogram(x, bins=16, range=(0, 1))
+    assert hist.min() > 0.9 * x.size / 16
+
+
+def test_oracle_tile_invariance():
+    """Rendering a tile equals the same pixels of the full frame (the sampler is keyed by pixel)."""
+    sc = S.room_planes(width=32, height=18)
+    o = pyref.restatement("f64").scene(sc)
+    full, _, _ = o.render(2, seed=1)
+    part, _, _ = o.render(2, seed=1, tile=(5, 3, 12, 9))
+    assert np.array_equal(full[3:12, 5:17], part[3:12, 5:17])
+    a, _, _ = o.render(1, seed=1, sample_begin=0)
+    b, _, _ = o.render(1, seed=1, sample_begin=1)
+    assert np.allclose(a + b, full, rtol=1e-14)

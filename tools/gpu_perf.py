@@ -1,0 +1,26 @@
+"""Quick perf probe (development tool)."""
+import importlib, sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+S = importlib.import_module("ray-tracing_amd.scenes")
+Rn = importlib.import_module("ray-tracing_amd.renderer")
+A = importlib.import_module("ray-tracing_amd._abi")
+tess = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+prec = sys.argv[3] if len(sys.argv) > 3 else "f32"
+cap = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+sc = S.room(1920, 1080, tess=tess)
+ctx = Rn.GpuContext(0)
+ctx.set_options(precision=prec, max_paths_in_flight=cap)
+t0 = time.time(); ctx.upload_scene(sc); print("upload", time.time() - t0)
+ctx.render_pass(0, 1); ctx.sync()
+ctx.reset_counters(); ctx.sync()
+t0 = time.time()
+ctx.render_pass(1, spp); ctx.sync()
+dt = time.time() - t0
+c = ctx.counters()
+rays = c.closest_rays + c.shadow_rays
+ns = 1920 * 1080 * spp
+print(f"{prec} tess={tess} spp={spp}: {dt:.3f}s  {ns/dt/1e6:.1f} Msamples/s  {rays/dt/1e9:.3f} Grays/s  rays/sample {rays/ns:.2f} launches {c.kernel_launches} overflow {c.stack_overflows}")
+rgb, n = ctx.read_film()
+print("mean", (rgb / n).mean())
