@@ -95,8 +95,19 @@ def main():
         anyhit = rs.trace_any(allrays)
         # consistency of the log with a replay through the same structure
         assert np.array_equal(closest["prim"][: len(log)][~is_any[: len(log)]], log["prim"][log["kind"] == 0])
+        # a second set for fp32 devices: rays cast by the float instantiation of the restatement, whose
+        # origins sit 1e-4 (not 1e-6) off the surfaces -- 1e-6 is below fp32 resolution at these
+        # coordinates, so the rays above are all near-ties for an fp32 tracer. Answers again from the
+        # real reference.
+        o32 = pyref.restatement("f32").scene(sc)
+        _, _, _, log32 = o32.render(2, threads=1, seed=3, record_rays=200000)
+        rays32 = np.zeros(len(log32), dtype=A.ray_dtype)
+        rays32["origin"], rays32["direction"], rays32["t_max"] = log32["o"], log32["d"], log32["t_max"]
+        c32 = rs.trace_closest(rays32)
+        a32 = rs.trace_any(rays32)
         np.savez_compressed(os.path.join(OUT, f"rays_{name}.npz"), builder=builder, kwargs=repr(kw), rays=allrays, logged_any=is_any,
-                            bvh_prim=closest["prim"], bvh_t=closest["t"], brute_prim=brute["prim"], brute_t=brute["t"], any_hit=anyhit, **meta)
+                            bvh_prim=closest["prim"], bvh_t=closest["t"], brute_prim=brute["prim"], brute_t=brute["t"], any_hit=anyhit,
+                            rays32=rays32, rays32_prim=c32["prim"], rays32_t=c32["t"], rays32_any=a32, n_random=len(rnd), **meta)
         print("rays", name, len(allrays), "bvh/brute prim mismatches", int((closest["prim"] != brute["prim"]).sum()))
         rs.close()
 
