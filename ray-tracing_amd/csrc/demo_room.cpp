@@ -1,0 +1,102 @@
+// demo_room.cpp -- C++ host using fcgpu::gpu_renderer exactly where the reference's main() uses
+// fc::renderer (src/main.cpp:3-12 -> src/example_scenes.hpp:187-263): the 10-primitive room
+// (6 wall planes, 1 plane emitter, the reference's three spheres), Forward MIS, writes room.raw.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fc_renderer.hpp"
+
+int main(int argc, char** argv)
+{
+    const int W = argc > 1 ? std::atoi(argv[1]) : 320, H = argc > 2 ? std::atoi(argv[2]) : 180;
+    const unsigned spp = argc > 3 ? static_cast<unsigned>(std::atoi(argv[3])) : 16;
+    const double pi = 3.141592653589793, h = pi / 2;
+    std::vector<fcgpu_surface> surfaces;
+    std::vector<fcgpu_material> materials;
+    std::vector<fcgpu_medium> media;
+    std::vector<fcgpu_entity> entities;
+    auto plane = [&](double x, double y, double z, double sx, double sz, double rx, double rz)
+    {
+        fcgpu_surface s{};
+        s.kind = FCGPU_SURFACE_PLANE;
+        s.position[0] = x; s.position[1] = y; s.position[2] = z;
+        s.rotation[0] = rx; s.rotation[2] = rz;
+        s.scale[0] = s.scale[1] = s.scale[2] = 1;
+        s.size[0] = sx; s.size[1] = sz;
+        surfaces.push_back(s);
+        return static_cast<int>(surfaces.size() - 1);
+    };
+    auto sphere = [&](double x, double y, double z, double r)
+    {
+        fcgpu_surface s{};
+        s.kind = FCGPU_SURFACE_SPHERE;
+        s.position[0] = x; s.position[1] = y; s.position[2] = z;
+        s.scale[0] = s.scale[1] = s.scale[2] = 1;
+        s.radius = r;
+        surfaces.push_back(s);
+        return static_cast<int>(surfaces.size() - 1);
+    };
+    auto material = [&](int kind, double r, double g, double b, double rough)
+    {
+        fcgpu_material m{};
+        m.kind = kind;
+        m.color_a[0] = r; m.color_a[1] = g; m.color_a[2] = b;
+        m.color_b[0] = m.color_b[1] = m.color_b[2] = 1;
+        m.roughness[0] = m.roughness[1] = rough;
+        materials.push_back(m);
+        return static_cast<int>(materials.size() - 1);
+    };
+    auto entity = [&](int surface, int mat, int medium, double strength)
+    {
+        fcgpu_entity e{};
+        e.surface = surface; e.material = mat; e.medium = medium;
+        e.emissive = strength > 0;
+        e.emission_color[0] = e.emission_color[1] = e.emission_color[2] = 1;
+        e.emission_strength = strength;
+        entities.push_back(e);
+    };
+    int white = material(FCGPU_MATERIAL_DIFFUSE, 0.8, 0.8, 0.8, 0);
+    entity(plane(0, 0, 5, 24, 30, 0, 0), white, -1, 0);
+    entity(plane(0, 8, 5, 24, 30, pi, 0), white, -1, 0);
+    entity(plane(-12, 4, 5, 8, 30, 0, -h), white, -1, 0);
+    entity(plane(12, 4, 5, 8, 30, 0, h), white, -1, 0);
+    entity(plane(0, 4, -10, 24, 8, h, 0), white, -1, 0);
+    entity(plane(0, 4, 20, 24, 8, -h, 0), white, -1, 0);
+    entity(plane(0, 7.9, 4, 3, 3, pi, 0), material(FCGPU_MATERIAL_DIFFUSE, 0.1, 0.1, 0.1, 0), -1, 250.0);
+    entity(sphere(4.2, 2.01, 0, 2), material(FCGPU_MATERIAL_DIFFUSE, 0.2, 0.4, 0.8, 0), -1, 0);
+    fcgpu_medium med{};
+    med.priority = 1; med.ior = 1.45; med.color[0] = 0.6; med.color[1] = 0.2; med.color[2] = 0.8; med.density = 0.5;
+    media.push_back(med);
+    entity(sphere(0, 2.01, 0, 2), material(FCGPU_MATERIAL_GLASS, 1, 1, 1, 0.3), 0, 0);
+    entity(sphere(-4.2, 2.01, 0, 2), material(FCGPU_MATERIAL_MIRROR, 0.8, 0.4, 0.2, 0.2), -1, 0);
+
+    fcgpu_scene_desc d{};
+    d.surfaces = surfaces.data(); d.surface_count = static_cast<uint32_t>(surfaces.size());
+    d.materials = materials.data(); d.material_count = static_cast<uint32_t>(materials.size());
+    d.media = media.data(); d.medium_count = static_cast<uint32_t>(media.size());
+    d.entities = entities.data(); d.entity_count = static_cast<uint32_t>(entities.size());
+    d.camera.position[0] = -7.23; d.camera.position[1] = 2.79; d.camera.position[2] = 16.37;
+    d.camera.rotation[0] = -4.641 / 180 * pi; d.camera.rotation[1] = 157.552 / 180 * pi;
+    d.camera.fov = 35.0 / 180 * pi;
+    d.camera.width = W; d.camera.height = H;
+    try
+    {
+        fcgpu::gpu_renderer renderer{d, fcgpu::integrator_desc{FCGPU_INTEGRATOR_MIS, 10, true}, spp};
+        renderer.run();
+        renderer.export_image("room");
+        std::uint64_t n = 0;
+        auto sum = renderer.film(&n);
+        double mean = 0;
+        for(double v : sum) mean += v;
+        std::printf("room.raw written: %dx%d, %u spp, mean %.6f, rays %llu\n", W, H, spp, mean / sum.size() / static_cast<double>(n),
+                    static_cast<unsigned long long>(renderer.counters().closest_rays + renderer.counters().shadow_rays));
+    }
+    catch(const std::exception& e)
+    {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

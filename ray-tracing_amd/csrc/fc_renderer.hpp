@@ -1,0 +1,86 @@
+// fc_renderer.hpp -- C++ host-side mirror of the reference's renderer over the C-ABI.
+//
+// `fcgpu::gpu_renderer` is shaped like `fc::renderer` (src/renderer/renderer.hpp:20-141):
+//     gpu_renderer r{scene_desc, integrator, sample_count, seed, device};  r.run();  r.export_image("room");
+// where `integrator` carries what `forward_mis_integrator{max_path_length, visible_infinity_area_light}`
+// (forward_mis_integrator.hpp:9-11) or `forward_bsdf_integrator{max_path_length}` carries.
+// Errors surface as std::runtime_error with the library's message (the C-ABI itself never throws).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/fcgpu.h"
+
+namespace fcgpu
+{
+    struct integrator_desc
+    {
+        int kind{FCGPU_INTEGRATOR_MIS};
+        int max_path_length{10};
+        bool visible_infinity_area_light{true};
+    };
+
+    class gpu_renderer
+    {
+    public:
+        gpu_renderer(const fcgpu_scene_desc& scene, integrator_desc integrator, std::uint32_t sample_count, std::uint64_t seed = 0,
+                     int device = 0, int precision = FCGPU_PRECISION_F32)
+            : integrator_{integrator}, sample_count_{sample_count}, width_{scene.camera.width}, height_{scene.camera.height}
+        {
+            if(fcgpu_create(device, &ctx_) != FCGPU_OK) throw std::runtime_error(fcgpu_last_error(nullptr));
+            fcgpu_options opt{};
+            opt.precision = precision;
+            opt.sort_materials = 1;
+            check(fcgpu_set_options(ctx_, &opt));
+            check(fcgpu_upload_scene(ctx_, &scene));
+            check(fcgpu_set_sampler(ctx_, seed));
+        }
+        gpu_renderer(const gpu_renderer&) = delete;
+        gpu_renderer& operator=(const gpu_renderer&) = delete;
+        ~gpu_renderer()
+        {
+            if(ctx_) fcgpu_destroy(ctx_);
+        }
+
+        // renderer::run (renderer.hpp:65-113): all pixels, all samples; `tile` restricts to a rectangle
+        void run(const fcgpu_tile* tile = nullptr)
+        {
+            check(fcgpu_render_pass(ctx_, tile, 0, sample_count_, integrator_.kind, integrator_.max_path_length,
+                                    integrator_.visible_infinity_area_light ? 1 : 0));
+            check(fcgpu_sync(ctx_));
+        }
+
+        // renderer::export_image (renderer.hpp:115-141): `<name>.raw`, float32 RGB, top row first
+        void export_image(const std::string& name) { check(fcgpu_export_image(ctx_, name.c_str())); }
+
+        // the operands of export_image's division
+        std::vector<double> film(std::uint64_t* sample_count)
+        {
+            std::vector<double> sum(3u * static_cast<std::size_t>(width_) * static_cast<std::size_t>(height_));
+            check(fcgpu_read_film(ctx_, sum.data(), sample_count));
+            return sum;
+        }
+
+        fcgpu_counters counters()
+        {
+            fcgpu_counters c{};
+            check(fcgpu_get_counters(ctx_, &c));
+            return c;
+        }
+
+        fcgpu_ctx* context() { return ctx_; }
+
+    private:
+        void check(int rc)
+        {
+            if(rc != FCGPU_OK) throw std::runtime_error(std::string("fcgpu error ") + std::to_string(rc) + ": " + fcgpu_last_error(ctx_));
+        }
+
+        fcgpu_ctx* ctx_{};
+        integrator_desc integrator_{};
+        std::uint32_t sample_count_{};
+        int width_{}, height_{};
+    };
+}
