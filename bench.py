@@ -71,7 +71,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:  # launched by torch.distributed.run (also exercised with one rank)
         import torch
         import torch.distributed as dist
 
@@ -88,7 +88,7 @@ def main():
     ctx.upload_scene(scene)
     ctx.set_sampler(0)
     film = None
-    if world > 1:
+    if dist is not None:
         D = importlib.import_module("ray-tracing_amd.distributed")
         film = torch.as_tensor(ctx.film_device_view(), device=torch.device("cuda", local))
 

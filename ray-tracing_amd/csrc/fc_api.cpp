@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -52,6 +53,7 @@ struct fcgpu_ctx
     uint64_t samples{};
     uint64_t launches{};
     int grid{};
+    int finish_min{16}, descend_min{12};  // traversal tuning, overridable through FCGPU_FINISH_MIN / FCGPU_DESCEND_MIN
     // stage profiling: a pool of event pairs drained at sync points
     bool profiling{};
     struct TimedSpan
@@ -180,16 +182,21 @@ namespace
         int rc;
         if((rc = col(&Q.ray_c0)) || (rc = col(&Q.ray_c1))) return rc;
         if((rc = col(&Q.sh_c0)) || (rc = col(&Q.sh_c1)) || (rc = col(&Q.sh_c2))) return rc;
-        // one hit queue per key that can occur in this scene (lobe types present, last vertex, miss)
+        if((rc = col(&Q.hit_c0)) || (rc = col(&Q.hit_c1))) return rc;
+        void* p = nullptr;
+        HIP_TRY(c, hipMalloc(&p, static_cast<size_t>(cap)));
+        c->queue_allocs.push_back(p);
+        Q.hit_key = static_cast<uint8_t*>(p);
+        // one index list per key that can occur in this scene (lobe types present, last vertex, miss)
         for(int k = 0; k < Q_COUNT; ++k)
         {
             bool needed = k == Q_FINAL || (k == Q_MISS && c->flat.env_kind != FCGPU_ENV_NONE) || (k < L_COUNT && (c->flat.lobe_mask >> k & 1u));
-            Q.hit_c0[k] = nullptr;
-            Q.hit_c1[k] = nullptr;
+            Q.hit_idx[k] = nullptr;
             if(!needed) continue;
-            if((rc = col(&Q.hit_c0[k])) || (rc = col(&Q.hit_c1[k]))) return rc;
+            HIP_TRY(c, hipMalloc(&p, sizeof(uint32_t) * static_cast<size_t>(cap)));
+            c->queue_allocs.push_back(p);
+            Q.hit_idx[k] = static_cast<uint32_t*>(p);
         }
-        void* p = nullptr;
         HIP_TRY(c, hipMalloc(&p, sizeof(PathState<R>) * static_cast<size_t>(cap)));
         c->queue_allocs.push_back(p);
         Q.state = static_cast<PathState<R>*>(p);
@@ -236,6 +243,8 @@ namespace
         B.visible_env = visible_env;
         B.W = c->flat.width;
         B.film = c->film;
+        B.finish_min = c->finish_min;
+        B.descend_min = c->descend_min;
 
         auto run_one = [&](uint32_t pix0, uint32_t npix, uint32_t s0, uint32_t nsamp)
         {
@@ -421,6 +430,9 @@ extern "C"
         hipDeviceProp_t prop{};
         if((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
         c->grid = std::max(1, prop.multiProcessorCount) * 8;
+        if(const char* e = std::getenv("FCGPU_FINISH_MIN")) c->finish_min = std::max(1, std::atoi(e));
+        if(const char* e = std::getenv("FCGPU_DESCEND_MIN")) c->descend_min = std::max(0, std::atoi(e));
+        if(const char* e = std::getenv("FCGPU_GRID_MULT")) c->grid = std::max(1, prop.multiProcessorCount) * std::max(1, std::atoi(e));
         *out = c;
         return FCGPU_OK;
     }
@@ -482,7 +494,6 @@ extern "C"
 
         SceneDev<float> a{};
         if((rc = upload(c, c->scene_allocs, c->flat.nodes, &a.nodes))) return rc;
-        if((rc = upload(c, c->scene_allocs, c->flat.leaf_prims, &a.leaf_prims))) return rc;
         if((rc = upload(c, c->scene_allocs, c->flat.tris, &a.tris))) return rc;
         if((rc = upload(c, c->scene_allocs, c->flat.tri_attrs, &a.tri_attrs))) return rc;
         if((rc = upload(c, c->scene_allocs, c->flat.prim_info, &a.prim_info))) return rc;
@@ -491,7 +502,6 @@ extern "C"
         if((rc = upload(c, c->scene_allocs, c->flat.light_cdf, &a.light_cdf))) return rc;
         SceneDev<double> b{};
         b.nodes = a.nodes;
-        b.leaf_prims = a.leaf_prims;
         b.tris = a.tris;
         b.tri_attrs = a.tri_attrs;
         b.prim_info = a.prim_info;
@@ -619,6 +629,8 @@ extern "C"
         out->reserved[0] = st[ST_MEDIUM_OVERFLOW];
         out->reserved[1] = c->flat.max_stack;
         out->reserved[2] = c->flat.binary_nodes;
+        out->reserved[3] = st[ST_NODES];
+        out->reserved[4] = st[ST_PRIMS];
         return FCGPU_OK;
     }
 

@@ -323,24 +323,46 @@ namespace fcg
         {
             BoxF box;
             bool leaf;
-            uint32_t bin;    // binary node (interior child)
-            uint32_t first;  // leaf: range in leaf_prims
+            uint32_t bin;    // interior child: binary node, or INVALID_U32 for a folded group (`first` = pending index)
+            uint32_t kind;   // leaf: primitive kind
+            uint32_t first;  // leaf: index into tris / xprims
             uint32_t count;
         };
 
+        // Collapses the binary tree into 4-wide nodes. Binary subtrees holding at most MAX_LEAF_PRIMS
+        // triangles become ONE leaf (a run of consecutive TriRec), which removes the bottom level of
+        // box tests and dependent loads; spheres and planes are single-primitive leaves.
         class WideBuilder
         {
         public:
-            WideBuilder(const BinaryBvh& bin, const std::vector<uint32_t>& prim_kind_index, FlatScene& out)
-                : bin_{bin}, kind_index_{prim_kind_index}, out_{out}
+            // order_box[k] / order_ki[k]: bounds and kind|index of the k-th primitive in binary leaf order
+            WideBuilder(const BinaryBvh& bin, const std::vector<BoxF>& order_box, const std::vector<uint32_t>& order_ki, FlatScene& out)
+                : bin_{bin}, order_box_{order_box}, order_ki_{order_ki}, out_{out}
             {
             }
 
             void run()
             {
-                // leaf_prims follows the binary leaf order, so a binary leaf [a, a+b) is the same range
-                out_.leaf_prims.resize(bin_.order.size());
-                for(size_t i = 0; i < bin_.order.size(); ++i) out_.leaf_prims[i] = kind_index_[bin_.order[i]];
+                // per binary node: its range in leaf order and whether it holds triangles only
+                range_.assign(bin_.nodes.size(), {0u, 0u});
+                tri_only_.assign(bin_.nodes.size(), 0);
+                for(size_t n = bin_.nodes.size(); n-- > 0;)
+                {
+                    const BinNode& b = bin_.nodes[n];
+                    if(!b.interior)
+                    {
+                        range_[n] = {b.a, static_cast<uint32_t>(b.b)};
+                        bool t = true;
+                        for(uint32_t k = b.a; k < b.a + b.b; ++k) t = t && (order_ki_[k] >> 30) == KIND_TRI;
+                        tri_only_[n] = t;
+                    }
+                    else
+                    {
+                        auto l = range_[n + 1], r = range_[b.a];
+                        range_[n] = {l.first, l.second + r.second};
+                        tri_only_[n] = tri_only_[n + 1] && tri_only_[b.a];
+                    }
+                }
                 std::vector<WideChild> kids;
                 gather(0, kids);
                 out_.max_stack = emit(kids);
@@ -348,40 +370,54 @@ namespace fcg
 
         private:
             const BinaryBvh& bin_;
-            const std::vector<uint32_t>& kind_index_;
+            const std::vector<BoxF>& order_box_;
+            const std::vector<uint32_t>& order_ki_;
             FlatScene& out_;
+            std::vector<std::pair<uint32_t, uint32_t>> range_;
+            std::vector<char> tri_only_;
 
-            void push_bin(uint32_t b, std::vector<WideChild>& kids, size_t at)
+            bool is_leafish(uint32_t b) const
             {
-                const BinNode& n = bin_.nodes[b];
-                if(n.interior)
+                return !bin_.nodes[b].interior || (tri_only_[b] && range_[b].second <= static_cast<uint32_t>(MAX_LEAF_PRIMS));
+            }
+
+            // leaf runs covering the primitives of binary node b, inserted at `at`
+            size_t push_runs(uint32_t b, std::vector<WideChild>& kids, size_t at)
+            {
+                uint32_t k = range_[b].first, end = k + range_[b].second;
+                size_t added = 0;
+                while(k < end)
                 {
-                    kids.insert(kids.begin() + at, WideChild{n.box, false, b, 0, 0});
-                    return;
+                    uint32_t kind = order_ki_[k] >> 30;
+                    uint32_t n = 1;
+                    if(kind == KIND_TRI)
+                        while(k + n < end && n < static_cast<uint32_t>(MAX_LEAF_PRIMS) && (order_ki_[k + n] >> 30) == KIND_TRI) ++n;
+                    BoxF box;
+                    for(uint32_t q = k; q < k + n; ++q) box.grow(order_box_[q]);
+                    kids.insert(kids.begin() + at + added, WideChild{box, true, 0u, kind, order_ki_[k] & 0x3FFFFFFFu, n});
+                    added += 1;
+                    k += n;
                 }
-                // a binary leaf wider than MAX_LEAF_PRIMS is cut into runs
-                uint32_t first = n.a, left = n.b;
-                std::vector<WideChild> runs;
-                while(left > 0)
-                {
-                    uint32_t c = std::min<uint32_t>(left, MAX_LEAF_PRIMS);
-                    runs.push_back(WideChild{n.box, true, 0, first, c});
-                    first += c;
-                    left -= c;
-                }
-                kids.insert(kids.begin() + at, runs.begin(), runs.end());
+                return added;
+            }
+
+            size_t push_bin(uint32_t b, std::vector<WideChild>& kids, size_t at)
+            {
+                if(is_leafish(b)) return push_runs(b, kids, at);
+                kids.insert(kids.begin() + at, WideChild{bin_.nodes[b].box, false, b, 0u, 0u, 0u});
+                return 1;
             }
 
             // children of binary node b, opened until four (largest surface area first)
             void gather(uint32_t b, std::vector<WideChild>& kids)
             {
                 kids.clear();
-                const BinNode& n = bin_.nodes[b];
-                if(!n.interior)
+                if(is_leafish(b))
                 {
-                    push_bin(b, kids, 0);
+                    push_runs(b, kids, 0);
                     return;
                 }
+                const BinNode& n = bin_.nodes[b];
                 push_bin(b + 1, kids, 0);
                 push_bin(n.a, kids, kids.size());
                 while(kids.size() < 4)
@@ -400,27 +436,23 @@ namespace fcg
                     uint32_t bb = kids[best].bin;
                     kids.erase(kids.begin() + best);
                     const BinNode& nb = bin_.nodes[bb];
-                    size_t before = kids.size();
-                    push_bin(bb + 1, kids, best);
-                    size_t added = kids.size() - before;
+                    size_t added = push_bin(bb + 1, kids, best);
                     push_bin(nb.a, kids, best + added);
-                    if(kids.size() > 4) break;  // only through wide-leaf runs; emit() groups the surplus
                 }
             }
 
-            // writes one wide node for `kids` (grouping surplus children under extra nodes) and
+            // writes one wide node for `kids` (folding surplus children under extra nodes) and
             // returns the worst-case stack depth needed below it
             uint32_t emit(std::vector<WideChild> kids)
             {
                 while(kids.size() > 4)
                 {
-                    // fold the trailing children into a sub-node (only for oversized leaves)
                     std::vector<WideChild> tail(kids.end() - 4, kids.end());
                     kids.erase(kids.end() - 4, kids.end());
                     BoxF b;
                     for(auto& k : tail) b.grow(k.box);
                     pending_.push_back(std::move(tail));
-                    kids.push_back(WideChild{b, false, INVALID_U32, static_cast<uint32_t>(pending_.size() - 1), 0});
+                    kids.push_back(WideChild{b, false, INVALID_U32, 0u, static_cast<uint32_t>(pending_.size() - 1), 0u});
                 }
 
                 uint32_t index = static_cast<uint32_t>(out_.nodes.size());
@@ -441,7 +473,7 @@ namespace fcg
                     const WideChild& k = kids[c];
                     if(k.leaf)
                     {
-                        node.child[c] = NODE_LEAF_BIT | ((k.count - 1) << 27) | k.first;
+                        node.child[c] = make_leaf(k.kind, k.first, k.count);
                     }
                     else
                     {
@@ -960,9 +992,9 @@ namespace fcg
             }
             out.entities.push_back(er);
         }
-        if(kind_index.size() >= (1u << 27))
+        if(kind_index.size() >= (1u << 26))
         {
-            err = "too many primitives (limit 2^27)";
+            err = "too many primitives (limit 2^26)";
             return FCGPU_E_LIMIT;
         }
 
@@ -1009,7 +1041,14 @@ namespace fcg
         if(out.tris.empty()) out.tris.push_back(TriRec{});
         if(out.tri_attrs.empty()) out.tri_attrs.push_back(TriAttr{});
 
-        WideBuilder wb{bin, kind_index, out};
+        std::vector<BoxF> order_box(bin.order.size());
+        std::vector<uint32_t> order_ki(bin.order.size());
+        for(size_t k = 0; k < bin.order.size(); ++k)
+        {
+            order_box[k] = refs[k].box;  // the build leaves refs in leaf order
+            order_ki[k] = kind_index[bin.order[k]];
+        }
+        WideBuilder wb{bin, order_box, order_ki, out};
         wb.run();
         if(out.max_stack > static_cast<uint32_t>(STACK_CAP))
         {

@@ -23,7 +23,6 @@ namespace fcg
     struct FlatScene
     {
         std::vector<Node4> nodes;
-        std::vector<uint32_t> leaf_prims;
         std::vector<TriRec> tris;
         std::vector<TriAttr> tri_attrs;
         std::vector<PrimInfo> prim_info;

@@ -19,6 +19,8 @@ namespace fcg
         int32_t visible_env;
         int32_t parity;              // which ray counter extend reads (shade writes parity ^ 1)
         int32_t W;                   // film width
+        int32_t finish_min;          // traversal tuning (see fc_traverse.h / k_extend)
+        int32_t descend_min;
         double* film;
     };
 

@@ -173,128 +173,228 @@ namespace fcg
     }
 
     // ------------------------------------------------------------------ extend
+    // Persistent waves with dynamic ray fetch: a lane whose ray is finished does not idle until the
+    // slowest ray of its wave ends; once FINISH_MIN lanes of the wave have finished (or nothing is
+    // left to traverse) they resolve their hits together and take new rays (work_take).
+
     template<typename R>
     __global__ __launch_bounds__(BLOCK) void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
-        __shared__ uint32_t stack[STACK_CAP * BLOCK];
-        __shared__ uint32_t q_lds[Q_COUNT][WAVES];
-        __shared__ uint32_t* q_ctr[Q_COUNT];
-        if(threadIdx.x < Q_COUNT) q_ctr[threadIdx.x] = &Q.counters->hit[threadIdx.x];
-        __syncthreads();
-
+        __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
+        uint32_t* stack = stack_lds + threadIdx.x;
         const uint32_t n = Q.counters->ray[B.parity];
-        uint32_t n_cast = 0, n_overflow = 0, n_moverflow = 0;
+        uint32_t n_cast = 0, n_overflow = 0, n_moverflow = 0, n_nodes = 0, n_prims = 0;
         const bool last = B.h >= B.max_len;
         // dimensions per bounce: 6 for forward_mis (fcgpu_sampler.h), 3 for forward_bsdf
         // (forward_bsdf_integrator.hpp:50,56: lobe pick, then u2, u1)
         const uint32_t dim_lobe = 2u + (B.integrator == FCGPU_INTEGRATOR_MIS ? 6u : 3u) * static_cast<uint32_t>(B.h - 1);
 
-        for(uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK)
+        WorkCursor W{0u, 0u, false};
+        Trav<R> T;
+        T.cur = INVALID_U32;
+        T.sp = 0;
+        uint32_t slot = INVALID_U32;  // ray-queue index this lane is working on
+        uint32_t path = 0, ms = 0;
+        vec3<R> dir{};
+        int guard = 0;
+
+        for(;;)
         {
-            const uint32_t i = base + threadIdx.x;
-            int key = -1;
-            Vec4<R> h0{}, h1{};
-            if(i < n)
+            const bool finished = slot != INVALID_U32 && trav_done(T);
+            const bool traversing = slot != INVALID_U32 && !trav_done(T);
+            const uint64_t any_trav = __ballot(traversing);
+            if(__popcll(__ballot(finished)) >= B.finish_min || any_trav == 0ull)
             {
-                Vec4<R> c0 = Q.ray_c0[i], c1 = Q.ray_c1[i];
-                uint32_t path, ms;
-                unpack_ids(c1, path, ms);
-                vec3<R> o{c0.x, c0.y, c0.z}, d{c0.w, c1.x, c1.y};
-                bool alive = false;
-                uint32_t prim = INVALID_U32, entity = 0;
-                vec3<R> p{}, nrm{};
-                R b0 = R(0), b1 = R(0);
-                // helper::raycast, integrator.hpp:33-109 (recursion -> loop)
-                for(int guard = 0; guard < 32; ++guard)
+                if(finished)
                 {
-                    RayCtx<R> rc = make_ray(o, d);
-                    R t;
-                    uint32_t pk;
-                    n_cast += 1;
-                    if(!traverse<R, false, BLOCK>(S, rc, consts<R>::inf, stack + threadIdx.x, t, pk, b0, b1, n_overflow)) break;
-                    hit_point(S, rc, pk, t, b0, b1, p, nrm, prim, entity);
-                    const uint32_t med = static_cast<uint32_t>(S.entities[entity].medium);
-                    const uint32_t top = medium_top(S, ms);
-                    if(med == 0u)
+                    // helper::raycast after scene.raycast returned, integrator.hpp:47-108 (recursion -> re-cast)
+                    int key = 0xFF;
+                    Vec4<R> h0{}, h1{};
+                    bool recast = false;
+                    bool alive = false;
+                    uint32_t prim = INVALID_U32, entity = 0;
+                    vec3<R> p{}, nrm{};
+                    if(T.pk != INVALID_U32)
                     {
-                        ms = ms_with_media(ms, top, top);
-                        alive = true;
-                        break;
-                    }
-                    const bool entering = dot(d, nrm) <= R(0);
-                    if(entering)
-                    {
-                        if(S.media[med].priority <= S.media[top].priority)
+                        hit_point(S, T.rc, T.pk, T.t_max, T.b0, T.b1, p, nrm, prim, entity);
+                        const uint32_t med = static_cast<uint32_t>(S.entities[entity].medium);
+                        const uint32_t top = medium_top(S, ms);
+                        if(med == 0u)
                         {
-                            ms = medium_push(ms, med, n_moverflow);  // the re-cast leaves p INTO its medium, :36-44
-                            o = p - nrm * S.epsilon;                 // scene.hpp:86-93 with dot(n, w) <= 0
-                            continue;
+                            ms = ms_with_media(ms, top, top);
+                            alive = true;
                         }
-                        ms = ms_with_media(ms, top, med);
-                        alive = true;
-                        break;
+                        else if(dot(dir, nrm) <= R(0))  // entering
+                        {
+                            if(S.media[med].priority <= S.media[top].priority)
+                            {
+                                ms = medium_push(ms, med, n_moverflow);  // the re-cast leaves p INTO its medium, :36-44
+                                p = p - nrm * S.epsilon;                 // scene.hpp:86-93 with dot(n, w) <= 0
+                                recast = true;
+                            }
+                            else
+                            {
+                                ms = ms_with_media(ms, top, med);
+                                alive = true;
+                            }
+                        }
+                        else
+                        {
+                            uint32_t cnt = ms_count(ms), idx = 0;
+                            for(; idx < cnt; ++idx)
+                                if(ms_get(ms, idx) == med) break;
+                            if(idx < cnt)  // else: leaving a medium never entered, the path dies (:88)
+                            {
+                                ms = ms_set(ms, idx, ms_get(ms, cnt - 1));  // swap with last, :90-91
+                                ms = (ms & ~7u) | (cnt - 1);
+                                const uint32_t new_top = medium_top(S, ms);
+                                if(S.media[new_top].priority == S.media[top].priority)
+                                {
+                                    p = p + nrm * S.epsilon;
+                                    recast = true;
+                                }
+                                else
+                                {
+                                    ms = ms_with_media(ms, new_top, top);
+                                    alive = true;
+                                }
+                            }
+                        }
                     }
-                    uint32_t cnt = ms_count(ms), idx = 0;
-                    for(; idx < cnt; ++idx)
-                        if(ms_get(ms, idx) == med) break;
-                    if(idx == cnt) break;  // leaving a medium never entered: the path dies, :88
-                    ms = ms_set(ms, idx, ms_get(ms, cnt - 1));  // swap with last, :90-91
-                    ms = (ms & ~7u) | (cnt - 1);
-                    const uint32_t new_top = medium_top(S, ms);
-                    if(S.media[new_top].priority == S.media[top].priority)
+                    if(recast && ++guard < 32)
                     {
-                        o = p + nrm * S.epsilon;
-                        continue;
-                    }
-                    ms = ms_with_media(ms, new_top, top);
-                    alive = true;
-                    break;
-                }
-                if(alive)
-                {
-                    uint32_t lobe = 0;
-                    if(last)
-                    {
-                        key = Q_FINAL;
+                        trav_begin(T, p, dir, consts<R>::inf);
+                        n_cast += 1;
                     }
                     else
                     {
-                        // bsdf::sample_bxdf, bsdf.hpp:46-55, on draw `dim_lobe`.x
-                        const MaterialRec m = S.materials[S.entities[entity].material];
-                        uint64_t bits = fcgpu_sample_bits(slot_key(B, path), dim_lobe);
-                        double u = fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
-                        for(int l = m.lobe_count - 1; l >= 0; --l)
+                        if(alive)
                         {
-                            if(u > S.lobes[m.first_lobe + l].cdf)
+                            uint32_t lobe = 0;
+                            if(last)
                             {
-                                lobe = static_cast<uint32_t>(l);
-                                break;
+                                key = Q_FINAL;
                             }
+                            else
+                            {
+                                // bsdf::sample_bxdf, bsdf.hpp:46-55, on draw `dim_lobe`.x
+                                const MaterialRec m = S.materials[S.entities[entity].material];
+                                uint64_t bits = fcgpu_sample_bits(slot_key(B, path), dim_lobe);
+                                double u = fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
+                                for(int l = m.lobe_count - 1; l >= 0; --l)
+                                {
+                                    if(u > S.lobes[m.first_lobe + l].cdf)
+                                    {
+                                        lobe = static_cast<uint32_t>(l);
+                                        break;
+                                    }
+                                }
+                                key = S.lobes[m.first_lobe + lobe].type;
+                            }
+                            h0 = Vec4<R>{p.x, p.y, p.z, T.b0};
+                            h1.x = T.b1;
+                            h1.y = pack_word(R(0), ms);
+                            pack_ids(h1, prim | (lobe << 30), path);
                         }
-                        key = S.lobes[m.first_lobe + lobe].type;
+                        else if(S.env_kind != FCGPU_ENV_NONE)
+                        {
+                            key = Q_MISS;
+                            h1.y = pack_word(R(0), ms);
+                            pack_ids(h1, INVALID_U32, path);
+                        }
+                        if(key != 0xFF)
+                        {
+                            Q.hit_c0[slot] = h0;
+                            Q.hit_c1[slot] = h1;
+                        }
+                        Q.hit_key[slot] = static_cast<uint8_t>(key);
+                        slot = INVALID_U32;
                     }
-                    h0 = Vec4<R>{p.x, p.y, p.z, b0};
-                    h1.x = b1;
-                    h1.y = pack_word(R(0), ms);
-                    pack_ids(h1, prim | (lobe << 30), path);
                 }
-                else if(S.env_kind != FCGPU_ENV_NONE)
+                // idle lanes take new rays
+                uint32_t fresh = work_take(W, slot == INVALID_U32, &Q.counters->work_extend, n);
+                if(fresh != INVALID_U32)
                 {
-                    key = Q_MISS;
-                    h1.y = pack_word(R(0), ms);
-                    pack_ids(h1, INVALID_U32, path);
+                    slot = fresh;
+                    Vec4<R> c0 = Q.ray_c0[slot], c1 = Q.ray_c1[slot];
+                    unpack_ids(c1, path, ms);
+                    dir = vec3<R>{c0.w, c1.x, c1.y};
+                    trav_begin(T, vec3<R>{c0.x, c0.y, c0.z}, dir, consts<R>::inf);
+                    n_cast += 1;
+                    guard = 0;
                 }
+                if(__ballot(slot != INVALID_U32) == 0ull) break;
             }
-            uint32_t slot = block_append<Q_COUNT>(key, q_ctr, q_lds);
-            if(key >= 0)
-            {
-                Q.hit_c0[key][slot] = h0;
-                Q.hit_c1[key][slot] = h1;
-            }
+            trav_round<R, false, BLOCK>(S, T, stack, n_overflow, B.descend_min, n_nodes, n_prims);
         }
         wave_stat_add(Q.stats, ST_CLOSEST, n_cast);
         wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow);
         wave_stat_add(Q.stats, ST_MEDIUM_OVERFLOW, n_moverflow);
+        wave_stat_add(Q.stats, ST_NODES, n_nodes);
+        wave_stat_add(Q.stats, ST_PRIMS, n_prims);
+    }
+
+    // material sort: index lists per queue key from hit_key[]. Each thread owns SORT_ITEMS consecutive
+    // hits, so a block compacts BLOCK * SORT_ITEMS hits with ONE global atomic per key.
+    constexpr int SORT_ITEMS = 8;
+
+    template<typename R>
+    __global__ __launch_bounds__(BLOCK) void k_sort(Wavefront<R> Q, Batch B)
+    {
+        __shared__ uint32_t cnt_lds[Q_COUNT][WAVES];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint64_t lt = (1ull << lane) - 1ull;
+        const uint32_t n = Q.counters->ray[B.parity];
+        for(uint32_t base = blockIdx.x * (BLOCK * SORT_ITEMS); base < n; base += gridDim.x * (BLOCK * SORT_ITEMS))
+        {
+            // item j of this thread is hit  base + j * BLOCK + threadIdx.x  (coalesced byte loads)
+            uint32_t key[SORT_ITEMS];
+            uint32_t pos[SORT_ITEMS];  // rank of the item among the wave's items of the same key
+            uint32_t wave_cnt = 0;     // lane k (< Q_COUNT) accumulates the wave's count of key k
+#pragma unroll
+            for(int j = 0; j < SORT_ITEMS; ++j)
+            {
+                uint32_t i = base + j * BLOCK + threadIdx.x;
+                key[j] = i < n ? Q.hit_key[i] : 0xFFu;
+                pos[j] = 0;
+            }
+#pragma unroll
+            for(int k = 0; k < Q_COUNT; ++k)
+            {
+                uint32_t run = 0;
+#pragma unroll
+                for(int j = 0; j < SORT_ITEMS; ++j)
+                {
+                    uint64_t m = __ballot(key[j] == static_cast<uint32_t>(k));
+                    if(key[j] == static_cast<uint32_t>(k)) pos[j] = run + __popcll(m & lt);
+                    run += __popcll(m);
+                }
+                if(lane == k) wave_cnt = run;
+            }
+            if(lane < Q_COUNT) cnt_lds[lane][wave] = wave_cnt;
+            __syncthreads();
+            if(threadIdx.x < Q_COUNT)
+            {
+                uint32_t total = 0;
+#pragma unroll
+                for(int w = 0; w < WAVES; ++w) total += cnt_lds[threadIdx.x][w];
+                uint32_t start = total ? atomicAdd(&Q.counters->hit[threadIdx.x], total) : 0u;
+#pragma unroll
+                for(int w = 0; w < WAVES; ++w)
+                {
+                    uint32_t c = cnt_lds[threadIdx.x][w];
+                    cnt_lds[threadIdx.x][w] = start;
+                    start += c;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for(int j = 0; j < SORT_ITEMS; ++j)
+            {
+                if(key[j] != 0xFFu) Q.hit_idx[key[j]][cnt_lds[key[j]][wave] + pos[j]] = base + j * BLOCK + threadIdx.x;
+            }
+            __syncthreads();
+        }
     }
 
     // ------------------------------------------------------------------ surface point reconstruction
@@ -438,8 +538,7 @@ namespace fcg
         const bool mis = B.integrator == FCGPU_INTEGRATOR_MIS;
         const uint32_t dim = 2u + (mis ? 6u : 3u) * static_cast<uint32_t>(B.h - 1);
         const uint32_t dim_u2 = dim + (mis ? 4u : 1u), dim_u1 = dim + (mis ? 5u : 2u);
-        const Vec4<R>* hit_c0 = Q.hit_c0[KEY];
-        const Vec4<R>* hit_c1 = Q.hit_c1[KEY];
+        const uint32_t* hit_idx = Q.hit_idx[KEY];
 
         for(uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK)
         {
@@ -448,7 +547,8 @@ namespace fcg
             Vec4<R> r0{}, r1{}, s0{}, s1{}, s2{};
             if(i < n)
             {
-                Vec4<R> h0 = hit_c0[i], h1 = hit_c1[i];
+                const uint32_t hi = hit_idx[i];
+                Vec4<R> h0 = Q.hit_c0[hi], h1 = Q.hit_c1[hi];
                 uint32_t prim_lobe, path;
                 unpack_ids(h1, prim_lobe, path);
                 uint32_t ms = unpack_word(h1.y);
@@ -629,7 +729,7 @@ namespace fcg
         const bool mis = B.integrator == FCGPU_INTEGRATOR_MIS;
         for(uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
         {
-            Vec4<R> h1 = Q.hit_c1[Q_MISS][i];
+            Vec4<R> h1 = Q.hit_c1[Q.hit_idx[Q_MISS][i]];
             uint32_t prim, path;
             unpack_ids(h1, prim, path);
             PathState<R>& st = Q.state[path];
@@ -659,33 +759,56 @@ namespace fcg
     template<typename R>
     __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
-        __shared__ uint32_t stack[STACK_CAP * BLOCK];
+        __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
+        uint32_t* stack = stack_lds + threadIdx.x;
         const uint32_t n = Q.counters->shadow;
-        uint32_t n_cast = 0, n_occ = 0, n_overflow = 0;
-        for(uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        uint32_t n_cast = 0, n_occ = 0, n_overflow = 0, n_nodes = 0, n_prims = 0;
+        WorkCursor W{0u, 0u, false};
+        Trav<R> T;
+        T.cur = INVALID_U32;
+        T.sp = 0;
+        uint32_t slot = INVALID_U32, path = 0;
+        for(;;)
         {
-            Vec4<R> c0 = Q.sh_c0[i], c1 = Q.sh_c1[i];
-            RayCtx<R> rc = make_ray(vec3<R>{c0.x, c0.y, c0.z}, vec3<R>{c0.w, c1.x, c1.y});
-            R t, b0, b1;
-            uint32_t pk;
-            n_cast += 1;
-            bool occluded = traverse<R, true, BLOCK>(S, rc, c1.z, stack + threadIdx.x, t, pk, b0, b1, n_overflow);
-            if(occluded)
+            const bool finished = slot != INVALID_U32 && trav_done(T);
+            const bool traversing = slot != INVALID_U32 && !trav_done(T);
+            if(__popcll(__ballot(finished)) >= B.finish_min || __ballot(traversing) == 0ull)
             {
-                n_occ += 1;
+                if(finished)
+                {
+                    if(T.pk != INVALID_U32)
+                    {
+                        n_occ += 1;
+                    }
+                    else
+                    {
+                        // unoccluded: the light-strategy term of forward_mis_integrator.hpp:84-91
+                        Vec4<R> c2 = Q.sh_c2[slot];
+                        PathState<R>& st = Q.state[path];
+                        st.Li[0] += c2.x;
+                        st.Li[1] += c2.y;
+                        st.Li[2] += c2.z;
+                    }
+                    slot = INVALID_U32;
+                }
+                uint32_t fresh = work_take(W, slot == INVALID_U32, &Q.counters->work_shadow, n);
+                if(fresh != INVALID_U32)
+                {
+                    slot = fresh;
+                    Vec4<R> c0 = Q.sh_c0[slot], c1 = Q.sh_c1[slot];
+                    path = unpack_word(c1.w);
+                    trav_begin(T, vec3<R>{c0.x, c0.y, c0.z}, vec3<R>{c0.w, c1.x, c1.y}, c1.z);
+                    n_cast += 1;
+                }
+                if(__ballot(slot != INVALID_U32) == 0ull) break;
             }
-            else
-            {
-                Vec4<R> c2 = Q.sh_c2[i];
-                PathState<R>& st = Q.state[unpack_word(c1.w)];
-                st.Li[0] += c2.x;
-                st.Li[1] += c2.y;
-                st.Li[2] += c2.z;
-            }
+            trav_round<R, true, BLOCK>(S, T, stack, n_overflow, B.descend_min, n_nodes, n_prims);
         }
         wave_stat_add(Q.stats, ST_SHADOW, n_cast);
         wave_stat_add(Q.stats, ST_OCCLUDED, n_occ);
         wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow);
+        wave_stat_add(Q.stats, ST_NODES, n_nodes);
+        wave_stat_add(Q.stats, ST_PRIMS, n_prims);
     }
 
     // ------------------------------------------------------------------ accumulate
@@ -730,6 +853,8 @@ namespace fcg
         {
             c->ray[parity_to_keep ^ 1] = 0;
             c->shadow = 0;
+            c->work_extend = 0;
+            c->work_shadow = 0;
         }
     }
 
@@ -783,6 +908,7 @@ namespace fcg
     template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
         hipLaunchKernelGGL(k_extend<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
+        hipLaunchKernelGGL(k_sort<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, Q, B);
     }
     template<typename R> void launch_shade(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key)
     {

@@ -147,114 +147,215 @@ namespace fcg
         b = hi;
     }
 
-    struct HitRaw
-    {
-        uint32_t pk;  // leaf_prims word (kind | index) or INVALID_U32
-    };
-
-    // Closest hit (ANY = false): returns true and fills t / pk / b0 / b1 when something is hit in (0, t_max].
-    // Any hit (ANY = true): returns true at the first primitive hit.
-    // `stack` points at this lane's column: entry k is stack[k * STRIDE].
+    // One node step: slab-tests the four quantised child boxes of `cur`, pushes the hit children that
+    // are not taken (far ones first) and returns the nearest one (or INVALID_U32 when none is hit).
     template<typename R, bool ANY, int STRIDE>
-    FC_D bool traverse(const SceneDev<R>& S, const RayCtx<R>& rc, R t_max, uint32_t* stack, R& t_out, uint32_t& pk_out,
-                       R& b0_out, R& b1_out, uint32_t& overflow)
+    FC_D uint32_t node_step(const SceneDev<R>& S, const RayCtx<R>& rc, R t_max, uint32_t cur, uint32_t* stack, int& sp, uint32_t& overflow)
     {
-        uint32_t best_pk = INVALID_U32;
-        R best_b0 = R(0), best_b1 = R(0);
-        int sp = 0;
-        uint32_t cur = 0;  // root is always a wide node
-        for(;;)
+        const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
+        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        R ox = R(__builtin_bit_cast(float, n0.x)), oy = R(__builtin_bit_cast(float, n0.y)), oz = R(__builtin_bit_cast(float, n0.z));
+        R ax = exp2_from_biased<R>(n0.w & 0xFFu) * rc.inv_d.x;
+        R ay = exp2_from_biased<R>((n0.w >> 8) & 0xFFu) * rc.inv_d.y;
+        R az = exp2_from_biased<R>((n0.w >> 16) & 0xFFu) * rc.inv_d.z;
+        R bx = (ox - rc.o.x) * rc.inv_d.x, by = (oy - rc.o.y) * rc.inv_d.y, bz = (oz - rc.o.z) * rc.inv_d.z;
+        uint32_t qlx = n1.x, qly = n1.y, qlz = n1.z, qhx = n1.w, qhy = n2.x, qhz = n2.y;
+        uint32_t ch[4]{n3.x, n3.y, n3.z, n3.w};
+        uint32_t key[4];
+#pragma unroll
+        for(int c = 0; c < 4; ++c)
         {
-            if(!child_is_leaf(cur))
+            R lx = R((qlx >> (8 * c)) & 0xFFu) * ax + bx, hx = R((qhx >> (8 * c)) & 0xFFu) * ax + bx;
+            R ly = R((qly >> (8 * c)) & 0xFFu) * ay + by, hy = R((qhy >> (8 * c)) & 0xFFu) * ay + by;
+            R lz = R((qlz >> (8 * c)) & 0xFFu) * az + bz, hz = R((qhz >> (8 * c)) & 0xFFu) * az + bz;
+            R tn = r_max(r_max(r_min(lx, hx), r_min(ly, hy)), r_max(r_min(lz, hz), R(0)));
+            R tf = r_min(r_min(r_max(lx, hx), r_max(ly, hy)), r_min(r_max(lz, hz), t_max));
+            bool hit = (tn <= tf * R(1.0000005)) && (ch[c] != INVALID_U32);
+            key[c] = hit ? order_key(tn, static_cast<uint32_t>(c)) : INVALID_U32;
+        }
+        if(!ANY)
+        {
+            cswap(key[0], key[1]);
+            cswap(key[2], key[3]);
+            cswap(key[0], key[2]);
+            cswap(key[1], key[3]);
+            cswap(key[1], key[2]);
+        }
+        uint32_t next = INVALID_U32;
+#pragma unroll
+        for(int k = 3; k >= 0; --k)
+        {
+            if(key[k] != INVALID_U32)
             {
-                const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
-                uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                R ox = R(__builtin_bit_cast(float, n0.x)), oy = R(__builtin_bit_cast(float, n0.y)), oz = R(__builtin_bit_cast(float, n0.z));
-                R ax = exp2_from_biased<R>(n0.w & 0xFFu) * rc.inv_d.x;
-                R ay = exp2_from_biased<R>((n0.w >> 8) & 0xFFu) * rc.inv_d.y;
-                R az = exp2_from_biased<R>((n0.w >> 16) & 0xFFu) * rc.inv_d.z;
-                R bx = (ox - rc.o.x) * rc.inv_d.x, by = (oy - rc.o.y) * rc.inv_d.y, bz = (oz - rc.o.z) * rc.inv_d.z;
-                uint32_t qlx = n1.x, qly = n1.y, qlz = n1.z, qhx = n1.w, qhy = n2.x, qhz = n2.y;
-                uint32_t ch[4]{n3.x, n3.y, n3.z, n3.w};
-                uint32_t key[4];
-#pragma unroll
-                for(int c = 0; c < 4; ++c)
-                {
-                    R lx = R((qlx >> (8 * c)) & 0xFFu) * ax + bx, hx = R((qhx >> (8 * c)) & 0xFFu) * ax + bx;
-                    R ly = R((qly >> (8 * c)) & 0xFFu) * ay + by, hy = R((qhy >> (8 * c)) & 0xFFu) * ay + by;
-                    R lz = R((qlz >> (8 * c)) & 0xFFu) * az + bz, hz = R((qhz >> (8 * c)) & 0xFFu) * az + bz;
-                    R tn = r_max(r_max(r_min(lx, hx), r_min(ly, hy)), r_max(r_min(lz, hz), R(0)));
-                    R tf = r_min(r_min(r_max(lx, hx), r_max(ly, hy)), r_min(r_max(lz, hz), t_max));
-                    bool hit = (tn <= tf * R(1.0000005)) && (ch[c] != INVALID_U32);
-                    key[c] = hit ? order_key(tn, static_cast<uint32_t>(c)) : INVALID_U32;
-                }
-                if(!ANY)
-                {
-                    cswap(key[0], key[1]);
-                    cswap(key[2], key[3]);
-                    cswap(key[0], key[2]);
-                    cswap(key[1], key[3]);
-                    cswap(key[1], key[2]);
-                }
-                // far children first so the nearest is popped first
-                uint32_t next = INVALID_U32;
-#pragma unroll
-                for(int k = 3; k >= 0; --k)
-                {
-                    if(key[k] != INVALID_U32)
-                    {
-                        uint32_t c = key[k] & 3u;
-                        uint32_t child = c == 0 ? ch[0] : (c == 1 ? ch[1] : (c == 2 ? ch[2] : ch[3]));
-                        if(next != INVALID_U32)
-                        {
-                            if(sp < STACK_CAP)
-                                stack[(sp++) * STRIDE] = next;
-                            else
-                                overflow += 1;
-                        }
-                        next = child;
-                    }
-                }
+                uint32_t c = key[k] & 3u;
+                uint32_t child = c == 0 ? ch[0] : (c == 1 ? ch[1] : (c == 2 ? ch[2] : ch[3]));
                 if(next != INVALID_U32)
                 {
-                    cur = next;
-                    continue;
+                    if(sp < STACK_CAP)
+                        stack[(sp++) * STRIDE] = next;
+                    else
+                        overflow += 1;
+                }
+                next = child;
+            }
+        }
+        return next;
+    }
+
+    // Resumable per-lane traversal state. pk = kind(2) | index(30) of the best primitive so far.
+    template<typename R>
+    struct Trav
+    {
+        RayCtx<R> rc;
+        R t_max;
+        R b0, b1;
+        uint32_t pk;
+        uint32_t cur;  // interior node index, leaf word, or INVALID_U32 = nothing left (leaf bit set)
+        int sp;
+    };
+
+    template<typename R> FC_D void trav_begin(Trav<R>& T, vec3<R> o, vec3<R> d, R t_max)
+    {
+        T.rc = make_ray(o, d);
+        T.t_max = t_max;
+        T.b0 = R(0);
+        T.b1 = R(0);
+        T.pk = INVALID_U32;
+        T.cur = 0;  // root is always a wide node
+        T.sp = 0;
+    }
+    template<typename R> FC_D bool trav_done(const Trav<R>& T) { return T.cur == INVALID_U32; }
+
+    // One round of the while-while traversal for the whole wave: every lane that holds an interior
+    // node descends until it holds a leaf (the descent loop ends early once fewer than DESCEND_MIN
+    // lanes are still descending while others wait with a leaf), then the lanes holding a leaf test
+    // its primitives together. Lanes with cur == INVALID_U32 idle through it.
+    // Closest hit (ANY = false): T.t_max / T.pk / T.b0 / T.b1 track the best hit; accepts t == t_max.
+    // Any hit (ANY = true): the first primitive hit sets T.pk and ends the lane's traversal.
+    // `stack` points at this lane's column: entry k is stack[k * STRIDE].
+
+    template<typename R, bool ANY, int STRIDE>
+    FC_D void trav_round(const SceneDev<R>& S, Trav<R>& T, uint32_t* stack, uint32_t& overflow, int descend_min, uint32_t& n_nodes, uint32_t& n_prims)
+    {
+        uint32_t cur = T.cur;
+        int sp = T.sp;
+        bool leaf_waiting = __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
+        while(!child_is_leaf(cur))
+        {
+            uint32_t next = node_step<R, ANY, STRIDE>(S, T.rc, T.t_max, cur, stack, sp, overflow);
+            n_nodes += 1;
+            if(next == INVALID_U32 && sp > 0) next = stack[(--sp) * STRIDE];
+            cur = next;
+            leaf_waiting = leaf_waiting || __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
+            if(leaf_waiting && __popcll(__ballot(!child_is_leaf(cur))) < descend_min) break;
+        }
+        if(child_is_leaf(cur) && cur != INVALID_U32)
+        {
+            const uint32_t first = leaf_first(cur), kind = leaf_kind(cur);
+            bool stop = false;
+            if(kind == KIND_TRI)
+            {
+                const uint32_t count = leaf_count(cur);
+                n_prims += count;
+                for(uint32_t j = 0; j < count; ++j)
+                {
+                    R t, b0, b1;
+                    if(tri_intersect(S.tris[first + j], T.rc, T.t_max, t, b0, b1))
+                    {
+                        T.t_max = t;
+                        T.pk = (KIND_TRI << 30) | (first + j);
+                        T.b0 = b0;
+                        T.b1 = b1;
+                        if(ANY)
+                        {
+                            stop = true;
+                            break;
+                        }
+                    }
                 }
             }
             else
             {
-                uint32_t first = leaf_first(cur), count = leaf_count(cur);
-                for(uint32_t j = 0; j < count; ++j)
+                R t;
+                n_prims += 1;
+                bool hit = kind == KIND_SPHERE ? sphere_intersect(S.xprims[first], T.rc, T.t_max, t) : plane_intersect(S.xprims[first], T.rc, T.t_max, t);
+                if(hit)
                 {
-                    uint32_t pk = S.leaf_prims[first + j];
-                    uint32_t kind = pk >> 30, idx = pk & 0x3FFFFFFFu;
-                    R t, b0 = R(0), b1 = R(0);
-                    bool hit;
-                    if(kind == KIND_TRI)
-                        hit = tri_intersect(S.tris[idx], rc, t_max, t, b0, b1);
-                    else if(kind == KIND_SPHERE)
-                        hit = sphere_intersect(S.xprims[idx], rc, t_max, t);
-                    else
-                        hit = plane_intersect(S.xprims[idx], rc, t_max, t);
-                    if(hit)
-                    {
-                        if(ANY) return true;
-                        t_max = t;
-                        best_pk = pk;
-                        best_b0 = b0;
-                        best_b1 = b1;
-                    }
+                    T.t_max = t;
+                    T.pk = (kind << 30) | first;
+                    T.b0 = R(0);
+                    T.b1 = R(0);
+                    if(ANY) stop = true;
                 }
             }
-            if(sp == 0) break;
-            cur = stack[(--sp) * STRIDE];
+            cur = (!stop && sp > 0) ? stack[(--sp) * STRIDE] : INVALID_U32;
         }
-        if(ANY) return false;
-        t_out = t_max;
-        pk_out = best_pk;
-        b0_out = best_b0;
-        b1_out = best_b1;
-        return best_pk != INVALID_U32;
+        T.cur = cur;
+        T.sp = sp;
+    }
+
+    // Whole-ray convenience wrapper (parity hooks): runs rounds until this lane's ray is finished.
+    template<typename R, bool ANY, int STRIDE>
+    FC_D bool traverse(const SceneDev<R>& S, const RayCtx<R>& rc, R t_max, uint32_t* stack, R& t_out, uint32_t& pk_out,
+                       R& b0_out, R& b1_out, uint32_t& overflow)
+    {
+        Trav<R> T;
+        T.rc = rc;
+        T.t_max = t_max;
+        T.b0 = R(0);
+        T.b1 = R(0);
+        T.pk = INVALID_U32;
+        T.cur = 0;
+        T.sp = 0;
+        uint32_t nn = 0, np = 0;
+        while(!trav_done(T)) trav_round<R, ANY, STRIDE>(S, T, stack, overflow, 12, nn, np);
+        t_out = T.t_max;
+        pk_out = T.pk;
+        b0_out = T.b0;
+        b1_out = T.b1;
+        return T.pk != INVALID_U32;
+    }
+
+    // Wave-level dynamic work distribution: idle lanes take the next ray indices from the wave's
+    // current chunk; an exhausted chunk is replaced with ONE global atomic (WORK_CHUNK rays), so a
+    // launch issues n / WORK_CHUNK atomics on the work counter (a single word serves ~88 atomics/us).
+    constexpr uint32_t WORK_CHUNK = 256;
+
+    struct WorkCursor
+    {
+        uint32_t cur, end;  // wave-uniform
+        bool dry;           // wave-uniform: the global counter ran past n
+    };
+
+    // returns this lane's new ray index or INVALID_U32; `want` = lane is idle
+    FC_D uint32_t work_take(WorkCursor& W, bool want, uint32_t* counter, uint32_t n)
+    {
+        uint32_t mine = INVALID_U32;
+        for(;;)
+        {
+            uint64_t m = __ballot(want && mine == INVALID_U32);
+            uint32_t cnt = __popcll(m);
+            if(cnt == 0u) break;
+            if(W.cur >= W.end)
+            {
+                if(W.dry) break;
+                uint32_t base = 0;
+                if((threadIdx.x & 63) == 0) base = atomicAdd(counter, WORK_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if(base >= n)
+                {
+                    W.dry = true;
+                    break;
+                }
+                W.cur = base;
+                W.end = base + WORK_CHUNK < n ? base + WORK_CHUNK : n;
+            }
+            uint32_t avail = W.end - W.cur;
+            uint32_t rank = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+            if(want && mine == INVALID_U32 && rank < avail) mine = W.cur + rank;
+            W.cur += cnt < avail ? cnt : avail;
+        }
+        return mine;
     }
 
     // geometry of a hit: world position and geometric normal, as the reference's raycast_surface_point builds them

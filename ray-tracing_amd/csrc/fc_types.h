@@ -4,7 +4,6 @@
 //   nodes      Node4[ ]     64-B 4-wide BVH nodes, child boxes quantised to 8 bit on a
 //                           per-node power-of-two grid, SoA inside the node (x/y/z planes as
 //                           the four bytes of one dword -> v_cvt_f32_ubyte0..3 decode).
-//   leaf_prims u32[ ]       kind(2) | index(30), in BVH leaf order
 //   tris       TriRec[ ]    48-B pre-gathered triangles in BVH leaf order (float vertices, as
 //                           mesh_surface stores them: mesh_surface.hpp:306)
 //   xprims     XPrim<R>[ ]  spheres / planes with their object<->world transforms
@@ -20,7 +19,7 @@ namespace fcg
 
     // ---- BVH
     constexpr uint32_t NODE_LEAF_BIT = 0x80000000u;
-    constexpr int MAX_LEAF_PRIMS = 16;
+    constexpr int MAX_LEAF_PRIMS = 4;   // triangles per leaf run (spheres / planes: one per leaf)
     constexpr int STACK_CAP = 32;  // LDS traversal stack entries per lane
 
     struct alignas(16) Node4
@@ -30,13 +29,16 @@ namespace fcg
         uint32_t qlo[3];        // per axis: byte c = quantised lower bound of child c
         uint32_t qhi[3];        // per axis: byte c = quantised upper bound of child c
         uint32_t pad[2];
-        uint32_t child[4];      // interior: node index; leaf: NODE_LEAF_BIT | (count-1)<<27 | first; empty: INVALID_U32
+        uint32_t child[4];      // interior: node index; leaf: NODE_LEAF_BIT | kind<<29 | (count-1)<<26 | first; empty: INVALID_U32
     };
     static_assert(sizeof(Node4) == 64, "Node4 must be one 64-byte line");
 
     FC_HD bool child_is_leaf(uint32_t c) { return (c & NODE_LEAF_BIT) != 0; }
-    FC_HD uint32_t leaf_first(uint32_t c) { return c & 0x07FFFFFFu; }
-    FC_HD uint32_t leaf_count(uint32_t c) { return ((c >> 27) & 0xFu) + 1u; }
+    // leaf word: first = index into tris (KIND_TRI, `count` consecutive records) or xprims (count 1)
+    FC_HD uint32_t leaf_first(uint32_t c) { return c & 0x03FFFFFFu; }
+    FC_HD uint32_t leaf_count(uint32_t c) { return ((c >> 26) & 0x7u) + 1u; }
+    FC_HD uint32_t leaf_kind(uint32_t c) { return (c >> 29) & 0x3u; }
+    FC_HD uint32_t make_leaf(uint32_t kind, uint32_t first, uint32_t count) { return NODE_LEAF_BIT | (kind << 29) | ((count - 1u) << 26) | first; }
 
     constexpr uint32_t KIND_TRI = 0, KIND_SPHERE = 1, KIND_PLANE = 2;
 
@@ -157,7 +159,6 @@ namespace fcg
     struct SceneDev
     {
         const Node4* nodes;
-        const uint32_t* leaf_prims;
         const TriRec* tris;
         const TriAttr* tri_attrs;
         const XPrim<R>* xprims;
@@ -242,12 +243,14 @@ namespace fcg
         uint32_t hit[Q_COUNT];
         uint32_t ray[2];     // ping-pong: extension rays of this / the next bounce
         uint32_t shadow;
-        uint32_t pad[4];
+        uint32_t work_extend;  // dynamic work cursors of the two traversal kernels
+        uint32_t work_shadow;
+        uint32_t pad[2];
     };
 
     enum StatIndex
     {
-        ST_CLOSEST = 0, ST_SHADOW = 1, ST_OCCLUDED = 2, ST_NAN = 3, ST_STACK_OVERFLOW = 4, ST_MEDIUM_OVERFLOW = 5, ST_COUNT = 8
+        ST_CLOSEST = 0, ST_SHADOW = 1, ST_OCCLUDED = 2, ST_NAN = 3, ST_STACK_OVERFLOW = 4, ST_MEDIUM_OVERFLOW = 5, ST_NODES = 6, ST_PRIMS = 7, ST_COUNT = 8
     };
 
     template<typename R>
@@ -256,9 +259,12 @@ namespace fcg
         // extension rays: c0 = {o.xyz, d.x}, c1 = {d.y, d.z, ids(path, mstack)}
         Vec4<R>* ray_c0;
         Vec4<R>* ray_c1;
-        // hits per key: c0 = {p.xyz, b0}, c1 = {b1, word(mstack), ids(prim|lobe<<30, path)}
-        Vec4<R>* hit_c0[Q_COUNT];
-        Vec4<R>* hit_c1[Q_COUNT];
+        // hits, in ray-queue order: c0 = {p.xyz, b0}, c1 = {b1, word(mstack), ids(prim|lobe<<30, path)};
+        // hit_key[i] = queue key of hit i (0xFF = path ended); hit_idx[k] = indices of the hits with key k
+        Vec4<R>* hit_c0;
+        Vec4<R>* hit_c1;
+        uint8_t* hit_key;
+        uint32_t* hit_idx[Q_COUNT];
         // shadow rays: c0 = {o.xyz, d.x}, c1 = {d.y, d.z, tmax, path}, c2 = {contribution rgb, -}
         Vec4<R>* sh_c0;
         Vec4<R>* sh_c1;

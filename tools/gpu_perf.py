@@ -23,4 +23,4 @@ rays = c.closest_rays + c.shadow_rays
 ns = 1920 * 1080 * spp
 print(f"{prec} tess={tess} spp={spp}: {dt:.3f}s  {ns/dt/1e6:.1f} Msamples/s  {rays/dt/1e9:.3f} Grays/s  rays/sample {rays/ns:.2f} launches {c.kernel_launches} overflow {c.stack_overflows}")
 rgb, n = ctx.read_film()
-print("mean", (rgb / n).mean())
+print("mean", (rgb / n).mean(), "nodes/ray", c.reserved[3]/rays, "prims/ray", c.reserved[4]/rays, "max_stack", c.reserved[1], "wide nodes", c.bvh_nodes)
