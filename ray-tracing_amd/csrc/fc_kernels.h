@@ -28,6 +28,7 @@ namespace fcg
     {
         hipStream_t stream;
         int grid;       // persistent grid size (blocks of 256)
+        int lds_pad_extend = 0, lds_pad_shadow = 0;  // extra dynamic LDS per block: caps the blocks per CU (tuning)
     };
 
     template<typename R> void launch_generate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);

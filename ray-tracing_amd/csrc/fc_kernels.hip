@@ -177,11 +177,14 @@ namespace fcg
     // slowest ray of its wave ends; once FINISH_MIN lanes of the wave have finished (or nothing is
     // left to traverse) they resolve their hits together and take new rays (work_take).
 
-    template<typename R>
+    template<typename R, bool PROF>
     __global__ __launch_bounds__(BLOCK) void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
+        unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};  // PROF: descent, leaf cycles, trips, leaf phases, finish cycles, finish phases
         __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
+        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
         uint32_t* stack = stack_lds + threadIdx.x;
+        unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
         const uint32_t n = Q.counters->ray[B.parity];
         uint32_t n_cast = 0, n_overflow = 0, n_moverflow = 0, n_nodes = 0, n_prims = 0;
         const bool last = B.h >= B.max_len;
@@ -189,7 +192,7 @@ namespace fcg
         // (forward_bsdf_integrator.hpp:50,56: lobe pick, then u2, u1)
         const uint32_t dim_lobe = 2u + (B.integrator == FCGPU_INTEGRATOR_MIS ? 6u : 3u) * static_cast<uint32_t>(B.h - 1);
 
-        WorkCursor W{0u, 0u, false};
+        WorkCursor W = work_begin();
         Trav<R> T;
         T.cur = INVALID_U32;
         T.sp = 0;
@@ -197,6 +200,9 @@ namespace fcg
         uint32_t path = 0, ms = 0;
         vec3<R> dir{};
         int guard = 0;
+        unsigned long long t_start = 0;
+        uint32_t n_rounds = 0;
+        if(PROF) t_start = wall_clock64();
 
         for(;;)
         {
@@ -205,6 +211,8 @@ namespace fcg
             const uint64_t any_trav = __ballot(traversing);
             if(__popcll(__ballot(finished)) >= B.finish_min || any_trav == 0ull)
             {
+                unsigned long long cf = 0;
+                if(PROF) cf = clock64();
                 if(finished)
                 {
                     // helper::raycast after scene.raycast returned, integrator.hpp:47-108 (recursion -> re-cast)
@@ -312,7 +320,7 @@ namespace fcg
                     }
                 }
                 // idle lanes take new rays
-                uint32_t fresh = work_take(W, slot == INVALID_U32, &Q.counters->work_extend, n);
+                uint32_t fresh = work_take(W, slot == INVALID_U32, Q.counters->work_extend, n);
                 if(fresh != INVALID_U32)
                 {
                     slot = fresh;
@@ -324,8 +332,40 @@ namespace fcg
                     guard = 0;
                 }
                 if(__ballot(slot != INVALID_U32) == 0ull) break;
+                if(PROF)
+                {
+                    ph[4] += clock64() - cf;
+                    ph[5] += 1;
+                }
             }
-            trav_round<R, false, BLOCK>(S, T, stack, n_overflow, B.descend_min, n_nodes, n_prims);
+            trav_round<R, false, BLOCK, PROF>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims, ph);
+            n_rounds += 1;
+        }
+        if(PROF)
+        {
+            uint32_t rays = n_cast, nodes = n_nodes, prims = n_prims, nodes_max = n_nodes, prims_max = n_prims;
+#pragma unroll
+            for(int o = 32; o > 0; o >>= 1)
+            {
+                rays += __shfl_down(rays, o);
+                nodes += __shfl_down(nodes, o);
+                prims += __shfl_down(prims, o);
+                nodes_max = max(nodes_max, static_cast<uint32_t>(__shfl_down(nodes_max, o)));
+                prims_max = max(prims_max, static_cast<uint32_t>(__shfl_down(prims_max, o)));
+            }
+            if((threadIdx.x & 63) == 0)
+            {
+                unsigned long long* t = Q.timeline + (static_cast<size_t>(blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 16u;
+                t[0] = t_start;
+                t[1] = wall_clock64();
+                t[2] = rays;
+                t[3] = n_rounds;
+                t[4] = nodes;
+                t[5] = nodes_max;
+                t[6] = prims;
+                t[7] = prims_max;
+                for(int k = 0; k < 6; ++k) t[8 + k] = ph[k];
+            }
         }
         wave_stat_add(Q.stats, ST_CLOSEST, n_cast);
         wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow);
@@ -760,10 +800,12 @@ namespace fcg
     __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
+        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
         uint32_t* stack = stack_lds + threadIdx.x;
+        unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
         const uint32_t n = Q.counters->shadow;
         uint32_t n_cast = 0, n_occ = 0, n_overflow = 0, n_nodes = 0, n_prims = 0;
-        WorkCursor W{0u, 0u, false};
+        WorkCursor W = work_begin();
         Trav<R> T;
         T.cur = INVALID_U32;
         T.sp = 0;
@@ -791,7 +833,7 @@ namespace fcg
                     }
                     slot = INVALID_U32;
                 }
-                uint32_t fresh = work_take(W, slot == INVALID_U32, &Q.counters->work_shadow, n);
+                uint32_t fresh = work_take(W, slot == INVALID_U32, Q.counters->work_shadow, n);
                 if(fresh != INVALID_U32)
                 {
                     slot = fresh;
@@ -802,7 +844,7 @@ namespace fcg
                 }
                 if(__ballot(slot != INVALID_U32) == 0ull) break;
             }
-            trav_round<R, true, BLOCK>(S, T, stack, n_overflow, B.descend_min, n_nodes, n_prims);
+            trav_round<R, true, BLOCK>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims);
         }
         wave_stat_add(Q.stats, ST_SHADOW, n_cast);
         wave_stat_add(Q.stats, ST_OCCLUDED, n_occ);
@@ -853,8 +895,11 @@ namespace fcg
         {
             c->ray[parity_to_keep ^ 1] = 0;
             c->shadow = 0;
-            c->work_extend = 0;
-            c->work_shadow = 0;
+        }
+        if(threadIdx.x < WORK_RANGES)
+        {
+            c->work_extend[threadIdx.x][0] = 0;
+            c->work_shadow[threadIdx.x][0] = 0;
         }
     }
 
@@ -864,10 +909,16 @@ namespace fcg
                                                      uint8_t* occluded, unsigned long long* stats)
     {
         __shared__ uint32_t stack[STACK_CAP * BLOCK];
+        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
+        unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
         uint32_t n_overflow = 0;
-        for(uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * BLOCK)
+        // block-uniform trip count: every lane of a wave takes part in the cooperative node fetches
+        for(uint64_t base = static_cast<uint64_t>(blockIdx.x) * BLOCK; base < n; base += static_cast<uint64_t>(gridDim.x) * BLOCK)
         {
-            const fcgpu_ray r = rays[i];
+            const uint64_t i = base + threadIdx.x;
+            const bool active = i < n;
+            fcgpu_ray r{};
+            if(active) r = rays[i];
             RayCtx<R> rc = make_ray(vec3<R>{R(r.origin[0]), R(r.origin[1]), R(r.origin[2])},
                                     vec3<R>{R(r.direction[0]), R(r.direction[1]), R(r.direction[2])});
             R t, b0, b1;
@@ -875,7 +926,8 @@ namespace fcg
             if(hits != nullptr)
             {
                 fcgpu_hit h{};
-                if(traverse<R, false, BLOCK>(S, rc, R(r.t_max), stack + threadIdx.x, t, pk, b0, b1, n_overflow))
+                const bool hit = traverse<R, false, BLOCK>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
+                if(hit)
                 {
                     vec3<R> p, nrm;
                     uint32_t prim, entity;
@@ -890,11 +942,12 @@ namespace fcg
                     h.t = __builtin_huge_val();
                     h.prim = INVALID_U32;
                 }
-                hits[i] = h;
+                if(active) hits[i] = h;
             }
             else
             {
-                occluded[i] = traverse<R, true, BLOCK>(S, rc, R(r.t_max), stack + threadIdx.x, t, pk, b0, b1, n_overflow) ? 1 : 0;
+                const bool hit = traverse<R, true, BLOCK>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
+                if(active) occluded[i] = hit ? 1 : 0;
             }
         }
         wave_stat_add(stats, ST_STACK_OVERFLOW, n_overflow);
@@ -907,7 +960,10 @@ namespace fcg
     }
     template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
-        hipLaunchKernelGGL(k_extend<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
+        if(Q.timeline)
+            hipLaunchKernelGGL((k_extend<R, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
+        else
+            hipLaunchKernelGGL((k_extend<R, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
         hipLaunchKernelGGL(k_sort<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, Q, B);
     }
     template<typename R> void launch_shade(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key)
@@ -929,7 +985,7 @@ namespace fcg
     }
     template<typename R> void launch_shadow(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
-        hipLaunchKernelGGL(k_shadow<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
+        hipLaunchKernelGGL(k_shadow<R>, dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
     }
     template<typename R> void launch_accumulate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {

@@ -17,6 +17,7 @@ namespace fcg
     struct RayCtx
     {
         vec3<R> o, d, inv_d;
+        bool negx, negy, negz;  // sign of each direction component: which slab plane is the near one
         int kx, ky, kz;  // mesh_surface.hpp:89-93
         R sx, sy, sz;    // mesh_surface.hpp:100-102
     };
@@ -39,6 +40,9 @@ namespace fcg
         rc.o = o;
         rc.d = d;
         rc.inv_d = vec3<R>{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
+        rc.negx = rc.inv_d.x < R(0);
+        rc.negy = rc.inv_d.y < R(0);
+        rc.negz = rc.inv_d.z < R(0);
         R ax = r_abs(d.x), ay = r_abs(d.y), az = r_abs(d.z);
         int kz = (ax > ay && ax > az) ? 0 : (ay > az ? 1 : 2);  // max_dimension, math.hpp:242-256
         int kx = kz + 1;
@@ -136,70 +140,161 @@ namespace fcg
         return __builtin_bit_cast(double, static_cast<uint64_t>(e + (1023u - 127u)) << 52);
     }
 
-    FC_D uint32_t order_key(float t, uint32_t c) { return (__builtin_bit_cast(uint32_t, t) & ~3u) | c; }
-    FC_D uint32_t order_key(double t, uint32_t c) { return order_key(static_cast<float>(t), c); }
+    FC_D uint32_t order_key(float t) { return __builtin_bit_cast(uint32_t, t); }  // t >= 0: bit order == value order
+    FC_D uint32_t order_key(double t) { return order_key(static_cast<float>(t)); }
 
-    FC_D void cswap(uint32_t& a, uint32_t& b)
+    // compare-exchange of (key, child) pairs: the smaller key ends in (ka, ca)
+    FC_D void cswap(uint32_t& ka, uint32_t& kb, uint32_t& ca, uint32_t& cb)
     {
-        uint32_t lo = a < b ? a : b;
-        uint32_t hi = a < b ? b : a;
-        a = lo;
-        b = hi;
+        bool s = kb < ka;
+        uint32_t k0 = s ? kb : ka, k1 = s ? ka : kb;
+        uint32_t c0 = s ? cb : ca, c1 = s ? ca : cb;
+        ka = k0;
+        kb = k1;
+        ca = c0;
+        cb = c1;
     }
+
+    template<typename R> FC_D R byte_to_real(uint32_t q, int c) { return R((q >> (8 * c)) & 0xFFu); }
+
+    // Entry / exit distances of the four child boxes: plane = q * a + b per axis (a = cell size / d,
+    // b = (grid origin - ray origin) / d), clipped to [0, t_max].
+    template<typename R>
+    struct slab4
+    {
+        static FC_D void run(uint32_t qnx, uint32_t qny, uint32_t qnz, uint32_t qfx, uint32_t qfy, uint32_t qfz, R ax, R ay, R az,
+                             R bx, R by, R bz, R t_max, R* tn, R* tf)
+        {
+#pragma unroll
+            for(int c = 0; c < 4; ++c)
+            {
+                R nx = byte_to_real<R>(qnx, c) * ax + bx, fx = byte_to_real<R>(qfx, c) * ax + bx;
+                R ny = byte_to_real<R>(qny, c) * ay + by, fy = byte_to_real<R>(qfy, c) * ay + by;
+                R nz = byte_to_real<R>(qnz, c) * az + bz, fz = byte_to_real<R>(qfz, c) * az + bz;
+                tn[c] = r_max(r_max(nx, ny), r_max(nz, R(0)));
+                tf[c] = r_min(r_min(fx, fy), r_min(fz, t_max));
+            }
+        }
+    };
+
+    // fp32: two children per v_pk_fma_f32 (packed fp32 issues two FMAs per lane per instruction on CDNA3/4)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    template<>
+    struct slab4<float>
+    {
+        static FC_D f32x2 planes(uint32_t q, int c, float a, float b)
+        {
+            f32x2 v{byte_to_real<float>(q, c), byte_to_real<float>(q, c + 1)};
+            return __builtin_elementwise_fma(v, f32x2{a, a}, f32x2{b, b});
+        }
+        static FC_D void run(uint32_t qnx, uint32_t qny, uint32_t qnz, uint32_t qfx, uint32_t qfy, uint32_t qfz, float ax, float ay,
+                             float az, float bx, float by, float bz, float t_max, float* tn, float* tf)
+        {
+#pragma unroll
+            for(int c = 0; c < 4; c += 2)
+            {
+                f32x2 nx = planes(qnx, c, ax, bx), fx = planes(qfx, c, ax, bx);
+                f32x2 ny = planes(qny, c, ay, by), fy = planes(qfy, c, ay, by);
+                f32x2 nz = planes(qnz, c, az, bz), fz = planes(qfz, c, az, bz);
+                tn[c] = r_max(r_max(nx.x, ny.x), r_max(nz.x, 0.0f));
+                tn[c + 1] = r_max(r_max(nx.y, ny.y), r_max(nz.y, 0.0f));
+                tf[c] = r_min(r_min(fx.x, fy.x), r_min(fz.x, t_max));
+                tf[c + 1] = r_min(r_min(fx.y, fy.y), r_min(fz.y, t_max));
+            }
+        }
+    };
 
     // One node step: slab-tests the four quantised child boxes of `cur`, pushes the hit children that
     // are not taken (far ones first) and returns the nearest one (or INVALID_U32 when none is hit).
+    // The near / far plane of every axis is picked by the sign of the ray direction (rc.neg*), which
+    // is what min/max of the two plane distances would give.
     template<typename R, bool ANY, int STRIDE>
-    FC_D uint32_t node_step(const SceneDev<R>& S, const RayCtx<R>& rc, R t_max, uint32_t cur, uint32_t* stack, int& sp, uint32_t& overflow)
+    FC_D uint32_t node_step(const RayCtx<R>& rc, R t_max, uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint32_t* stack, int& sp, uint32_t& overflow)
     {
-        const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
-        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
         R ox = R(__builtin_bit_cast(float, n0.x)), oy = R(__builtin_bit_cast(float, n0.y)), oz = R(__builtin_bit_cast(float, n0.z));
         R ax = exp2_from_biased<R>(n0.w & 0xFFu) * rc.inv_d.x;
         R ay = exp2_from_biased<R>((n0.w >> 8) & 0xFFu) * rc.inv_d.y;
         R az = exp2_from_biased<R>((n0.w >> 16) & 0xFFu) * rc.inv_d.z;
         R bx = (ox - rc.o.x) * rc.inv_d.x, by = (oy - rc.o.y) * rc.inv_d.y, bz = (oz - rc.o.z) * rc.inv_d.z;
-        uint32_t qlx = n1.x, qly = n1.y, qlz = n1.z, qhx = n1.w, qhy = n2.x, qhz = n2.y;
+        uint32_t qnx = rc.negx ? n1.w : n1.x, qfx = rc.negx ? n1.x : n1.w;
+        uint32_t qny = rc.negy ? n2.x : n1.y, qfy = rc.negy ? n1.y : n2.x;
+        uint32_t qnz = rc.negz ? n2.y : n1.z, qfz = rc.negz ? n1.z : n2.y;
         uint32_t ch[4]{n3.x, n3.y, n3.z, n3.w};
         uint32_t key[4];
+        R tn[4], tf[4];
+        slab4<R>::run(qnx, qny, qnz, qfx, qfy, qfz, ax, ay, az, bx, by, bz, t_max, tn, tf);
 #pragma unroll
         for(int c = 0; c < 4; ++c)
         {
-            R lx = R((qlx >> (8 * c)) & 0xFFu) * ax + bx, hx = R((qhx >> (8 * c)) & 0xFFu) * ax + bx;
-            R ly = R((qly >> (8 * c)) & 0xFFu) * ay + by, hy = R((qhy >> (8 * c)) & 0xFFu) * ay + by;
-            R lz = R((qlz >> (8 * c)) & 0xFFu) * az + bz, hz = R((qhz >> (8 * c)) & 0xFFu) * az + bz;
-            R tn = r_max(r_max(r_min(lx, hx), r_min(ly, hy)), r_max(r_min(lz, hz), R(0)));
-            R tf = r_min(r_min(r_max(lx, hx), r_max(ly, hy)), r_min(r_max(lz, hz), t_max));
-            bool hit = (tn <= tf * R(1.0000005)) && (ch[c] != INVALID_U32);
-            key[c] = hit ? order_key(tn, static_cast<uint32_t>(c)) : INVALID_U32;
+            bool hit = (tn[c] <= tf[c] * R(1.0000005)) && (ch[c] != INVALID_U32);
+            key[c] = hit ? order_key(tn[c]) : INVALID_U32;
         }
-        if(!ANY)
-        {
-            cswap(key[0], key[1]);
-            cswap(key[2], key[3]);
-            cswap(key[0], key[2]);
-            cswap(key[1], key[3]);
-            cswap(key[1], key[2]);
-        }
-        uint32_t next = INVALID_U32;
+        // sorting network on (entry distance, child) pairs; missed children (INVALID key) sink to the end.
+        // Occlusion rays (ANY) use it too: it is the cheapest way to compact the hit children.
+        cswap(key[0], key[1], ch[0], ch[1]);
+        cswap(key[2], key[3], ch[2], ch[3]);
+        cswap(key[0], key[2], ch[0], ch[2]);
+        cswap(key[1], key[3], ch[1], ch[3]);
+        cswap(key[1], key[2], ch[1], ch[2]);
+        uint32_t next = key[0] != INVALID_U32 ? ch[0] : INVALID_U32;
+        // the host refuses a BVH whose worst case exceeds STACK_CAP (FCGPU_E_LIMIT): `room` is always true
+        const bool room = sp <= STACK_CAP - 3;
+        overflow += (!room && key[1] != INVALID_U32) ? 1u : 0u;
 #pragma unroll
-        for(int k = 3; k >= 0; --k)
+        for(int k = 3; k >= 1; --k)
         {
-            if(key[k] != INVALID_U32)
-            {
-                uint32_t c = key[k] & 3u;
-                uint32_t child = c == 0 ? ch[0] : (c == 1 ? ch[1] : (c == 2 ? ch[2] : ch[3]));
-                if(next != INVALID_U32)
-                {
-                    if(sp < STACK_CAP)
-                        stack[(sp++) * STRIDE] = next;
-                    else
-                        overflow += 1;
-                }
-                next = child;
-            }
+            const bool push = room && key[k] != INVALID_U32;
+            if(push) stack[sp * STRIDE] = ch[k];
+            sp += push ? 1 : 0;
         }
         return next;
+    }
+
+    // Quad-cooperative node fetch (FCG_COOP_FETCH=1; off by default). A lane that loads its own
+    // 64-byte node with four 16-byte loads costs the L1 (TA/TCP) four tag cycles for one line. Here the
+    // four lanes of a quad load the four 16-byte pieces of ONE node per instruction (one line, one L1
+    // transaction), for each of the quad's four owners in turn, straight into LDS
+    // (global_load_lds_dwordx4: destination = wave base + lane * 16), and every owner then reads its
+    // node back with ds_read_b128. Measured (tools/micro/node_gather.hip): a saturated CU gathers
+    // 2200 random lines/us this way against 1000 with per-lane loads -- but traversal only asks for
+    // ~220 lines/us/CU, so it is latency that counts there, and the extra DPP + LDS round trip and the
+    // 16 KB of LDS per block made k_extend 3 % slower. Kept for scenes/hardware where the L1 saturates.
+    // Layout of a wave's buffer: slot k (owner = lane 4q+k) at k * NODEBUF_SLOT, quad q at + q * 64;
+    // the 16-byte skew between slots makes the read-back conflict-free.
+    // Every lane of the wave must execute this (wave-uniform control flow): a lane that holds no
+    // interior node still loads pieces for its quad mates.
+#ifndef FCG_COOP_FETCH
+#define FCG_COOP_FETCH 0
+#endif
+    constexpr int NODEBUF_SLOT = 64 * 16 + 16;
+    constexpr int NODEBUF_WAVE = FCG_COOP_FETCH ? 4 * NODEBUF_SLOT : 16;
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef const __attribute__((address_space(1))) void global_void_t;
+
+    template<int K>
+    FC_D void coop_fetch_slot(const Node4* nodes, uint32_t cur, unsigned char* nodebuf)
+    {
+        const uint32_t owner_cur = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(cur), K * 0x55, 0xF, 0xF, true));
+        if(!child_is_leaf(owner_cur))
+        {
+            const unsigned char* g = reinterpret_cast<const unsigned char*>(nodes) + static_cast<size_t>(owner_cur) * sizeof(Node4) + (threadIdx.x & 3u) * 16u;
+            __builtin_amdgcn_global_load_lds((global_void_t*)g, (lds_void_t*)(nodebuf + K * NODEBUF_SLOT), 16, 0, 0);
+        }
+    }
+
+    FC_D void coop_fetch_nodes(const Node4* nodes, uint32_t cur, unsigned char* nodebuf)
+    {
+        coop_fetch_slot<0>(nodes, cur, nodebuf);
+        coop_fetch_slot<1>(nodes, cur, nodebuf);
+        coop_fetch_slot<2>(nodes, cur, nodebuf);
+        coop_fetch_slot<3>(nodes, cur, nodebuf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    FC_D const uint4* coop_my_node(const unsigned char* nodebuf)
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        return reinterpret_cast<const uint4*>(nodebuf + (lane & 3u) * NODEBUF_SLOT + (lane >> 2) * 64u);
     }
 
     // Resumable per-lane traversal state. pk = kind(2) | index(30) of the best primitive so far.
@@ -232,22 +327,49 @@ namespace fcg
     // its primitives together. Lanes with cur == INVALID_U32 idle through it.
     // Closest hit (ANY = false): T.t_max / T.pk / T.b0 / T.b1 track the best hit; accepts t == t_max.
     // Any hit (ANY = true): the first primitive hit sets T.pk and ends the lane's traversal.
-    // `stack` points at this lane's column: entry k is stack[k * STRIDE].
+    // `stack` points at this lane's column: entry k is stack[k * STRIDE]; `nodebuf` is the wave's
+    // NODEBUF_WAVE-byte LDS staging area. All 64 lanes of the wave must call it together.
 
-    template<typename R, bool ANY, int STRIDE>
-    FC_D void trav_round(const SceneDev<R>& S, Trav<R>& T, uint32_t* stack, uint32_t& overflow, int descend_min, uint32_t& n_nodes, uint32_t& n_prims)
+    // PROF (development aid): ph[0] += clock cycles in the descent loop, ph[1] += cycles in the leaf
+    // phase, ph[2] += wave-level descent trips, ph[3] += leaf phases entered.
+    template<typename R, bool ANY, int STRIDE, bool PROF = false>
+    FC_D void trav_round(const SceneDev<R>& S, Trav<R>& T, uint32_t* stack, unsigned char* nodebuf, uint32_t& overflow, int descend_min,
+                         uint32_t& n_nodes, uint32_t& n_prims, unsigned long long* ph = nullptr)
     {
+        unsigned long long c0 = 0;
+        if(PROF) c0 = clock64();
         uint32_t cur = T.cur;
         int sp = T.sp;
         bool leaf_waiting = __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
-        while(!child_is_leaf(cur))
+        for(;;)
         {
-            uint32_t next = node_step<R, ANY, STRIDE>(S, T.rc, T.t_max, cur, stack, sp, overflow);
-            n_nodes += 1;
-            if(next == INVALID_U32 && sp > 0) next = stack[(--sp) * STRIDE];
-            cur = next;
+            const bool descending = !child_is_leaf(cur);
+            const uint64_t dm = __ballot(descending);
+            if(dm == 0ull || (leaf_waiting && __popcll(dm) < descend_min)) break;
+            if(PROF) ph[2] += 1;
+#if FCG_COOP_FETCH
+            coop_fetch_nodes(S.nodes, cur, nodebuf);
+#endif
+            if(descending)
+            {
+#if FCG_COOP_FETCH
+                const uint4* np = coop_my_node(nodebuf);
+#else
+                const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
+#endif
+                uint32_t next = node_step<R, ANY, STRIDE>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, sp, overflow);
+                n_nodes += 1;
+                if(next == INVALID_U32 && sp > 0) next = stack[(--sp) * STRIDE];
+                cur = next;
+            }
             leaf_waiting = leaf_waiting || __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
-            if(leaf_waiting && __popcll(__ballot(!child_is_leaf(cur))) < descend_min) break;
+        }
+        unsigned long long c1 = 0;
+        if(PROF)
+        {
+            c1 = clock64();
+            ph[0] += c1 - c0;
+            ph[3] += __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull ? 1 : 0;
         }
         if(child_is_leaf(cur) && cur != INVALID_U32)
         {
@@ -257,20 +379,23 @@ namespace fcg
             {
                 const uint32_t count = leaf_count(cur);
                 n_prims += count;
-                for(uint32_t j = 0; j < count; ++j)
+                // all records of the leaf are requested before the first test: one memory latency per
+                // leaf instead of one per triangle
+                TriRec tr[4];
+#pragma unroll
+                for(uint32_t j = 0; j < 4u; ++j)
+                    if(j < count) tr[j] = S.tris[first + j];
+#pragma unroll
+                for(uint32_t j = 0; j < 4u; ++j)
                 {
                     R t, b0, b1;
-                    if(tri_intersect(S.tris[first + j], T.rc, T.t_max, t, b0, b1))
+                    if(j < count && !stop && tri_intersect(tr[j], T.rc, T.t_max, t, b0, b1))
                     {
                         T.t_max = t;
                         T.pk = (KIND_TRI << 30) | (first + j);
                         T.b0 = b0;
                         T.b1 = b1;
-                        if(ANY)
-                        {
-                            stop = true;
-                            break;
-                        }
+                        if(ANY) stop = true;
                     }
                 }
             }
@@ -292,12 +417,14 @@ namespace fcg
         }
         T.cur = cur;
         T.sp = sp;
+        if(PROF) ph[1] += clock64() - c1;
     }
 
-    // Whole-ray convenience wrapper (parity hooks): runs rounds until this lane's ray is finished.
+    // Whole-wave convenience wrapper (parity hooks): runs rounds until every ray of the wave is finished.
+    // Lanes without a ray pass active = false (they still take part in the cooperative fetches).
     template<typename R, bool ANY, int STRIDE>
-    FC_D bool traverse(const SceneDev<R>& S, const RayCtx<R>& rc, R t_max, uint32_t* stack, R& t_out, uint32_t& pk_out,
-                       R& b0_out, R& b1_out, uint32_t& overflow)
+    FC_D bool traverse(const SceneDev<R>& S, bool active, const RayCtx<R>& rc, R t_max, uint32_t* stack, unsigned char* nodebuf, R& t_out,
+                       uint32_t& pk_out, R& b0_out, R& b1_out, uint32_t& overflow)
     {
         Trav<R> T;
         T.rc = rc;
@@ -305,10 +432,10 @@ namespace fcg
         T.b0 = R(0);
         T.b1 = R(0);
         T.pk = INVALID_U32;
-        T.cur = 0;
+        T.cur = active ? 0u : INVALID_U32;
         T.sp = 0;
         uint32_t nn = 0, np = 0;
-        while(!trav_done(T)) trav_round<R, ANY, STRIDE>(S, T, stack, overflow, 12, nn, np);
+        while(__ballot(!trav_done(T)) != 0ull) trav_round<R, ANY, STRIDE>(S, T, stack, nodebuf, overflow, 12, nn, np);
         t_out = T.t_max;
         pk_out = T.pk;
         b0_out = T.b0;
@@ -316,19 +443,28 @@ namespace fcg
         return T.pk != INVALID_U32;
     }
 
-    // Wave-level dynamic work distribution: idle lanes take the next ray indices from the wave's
-    // current chunk; an exhausted chunk is replaced with ONE global atomic (WORK_CHUNK rays), so a
-    // launch issues n / WORK_CHUNK atomics on the work counter (a single word serves ~88 atomics/us).
-    constexpr uint32_t WORK_CHUNK = 256;
+    // Wave-level dynamic work distribution. The ray queue is cut into WORK_RANGES equal ranges, each
+    // with its own cursor word; a wave starts in the range of its block (blockIdx & 7: blocks are dealt
+    // round-robin to the 8 XCDs, so a range is mostly served by one XCD) and moves on to the next range
+    // when its own is exhausted. Idle lanes take ray indices from the wave's current chunk; a new chunk
+    // costs ONE atomic per wave. Small chunks keep the end-of-launch tail short: when the cursors run
+    // dry every wave still has to finish at most WORK_CHUNK rays.
+#ifndef FCG_WORK_CHUNK
+#define FCG_WORK_CHUNK 64
+#endif
+    constexpr uint32_t WORK_CHUNK = FCG_WORK_CHUNK;
 
     struct WorkCursor
     {
-        uint32_t cur, end;  // wave-uniform
-        bool dry;           // wave-uniform: the global counter ran past n
+        uint32_t cur, end;     // wave-uniform: rest of the current chunk
+        uint32_t range, tried; // current range; ranges found exhausted (WORK_RANGES = nothing left)
     };
 
+    FC_D WorkCursor work_begin() { return WorkCursor{0u, 0u, blockIdx.x & (WORK_RANGES - 1), 0u}; }
+    FC_D uint32_t work_range_lo(uint32_t n, uint32_t r) { return static_cast<uint32_t>((static_cast<uint64_t>(n) * r) / WORK_RANGES); }
+
     // returns this lane's new ray index or INVALID_U32; `want` = lane is idle
-    FC_D uint32_t work_take(WorkCursor& W, bool want, uint32_t* counter, uint32_t n)
+    FC_D uint32_t work_take(WorkCursor& W, bool want, uint32_t (*counters)[32], uint32_t n)
     {
         uint32_t mine = INVALID_U32;
         for(;;)
@@ -338,17 +474,19 @@ namespace fcg
             if(cnt == 0u) break;
             if(W.cur >= W.end)
             {
-                if(W.dry) break;
+                if(W.tried >= static_cast<uint32_t>(WORK_RANGES)) break;
+                const uint32_t lo = work_range_lo(n, W.range), hi = work_range_lo(n, W.range + 1u);
                 uint32_t base = 0;
-                if((threadIdx.x & 63) == 0) base = atomicAdd(counter, WORK_CHUNK);
+                if((threadIdx.x & 63) == 0) base = atomicAdd(&counters[W.range][0], WORK_CHUNK);
                 base = __builtin_amdgcn_readfirstlane(base);
-                if(base >= n)
+                if(base >= hi - lo)
                 {
-                    W.dry = true;
-                    break;
+                    W.range = (W.range + 1u) & (WORK_RANGES - 1);
+                    W.tried += 1u;
+                    continue;
                 }
-                W.cur = base;
-                W.end = base + WORK_CHUNK < n ? base + WORK_CHUNK : n;
+                W.cur = lo + base;
+                W.end = hi - W.cur < WORK_CHUNK ? hi : W.cur + WORK_CHUNK;
             }
             uint32_t avail = W.end - W.cur;
             uint32_t rank = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));

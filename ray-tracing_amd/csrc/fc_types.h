@@ -20,7 +20,10 @@ namespace fcg
     // ---- BVH
     constexpr uint32_t NODE_LEAF_BIT = 0x80000000u;
     constexpr int MAX_LEAF_PRIMS = 4;   // triangles per leaf run (spheres / planes: one per leaf)
-    constexpr int STACK_CAP = 32;  // LDS traversal stack entries per lane
+#ifndef FCG_STACK_CAP
+#define FCG_STACK_CAP 30
+#endif
+    constexpr int STACK_CAP = FCG_STACK_CAP;  // LDS traversal stack entries per lane: 30 KB per 256-thread block, 5 blocks per CU
 
     struct alignas(16) Node4
     {
@@ -238,14 +241,18 @@ namespace fcg
         R pad2;
     };
 
+    constexpr int WORK_RANGES = 8;
+
     struct QueueCounters  // device-resident, zeroed per bounce
     {
         uint32_t hit[Q_COUNT];
         uint32_t ray[2];     // ping-pong: extension rays of this / the next bounce
         uint32_t shadow;
-        uint32_t work_extend;  // dynamic work cursors of the two traversal kernels
-        uint32_t work_shadow;
-        uint32_t pad[2];
+        uint32_t pad[4];
+        // dynamic work cursors of the two traversal kernels: one per ray-queue range, each on its own
+        // 128-byte line (a single word serves only ~88 atomics/us)
+        uint32_t work_extend[WORK_RANGES][32];
+        uint32_t work_shadow[WORK_RANGES][32];
     };
 
     enum StatIndex
@@ -272,6 +279,9 @@ namespace fcg
         PathState<R>* state;
         QueueCounters* counters;
         unsigned long long* stats;
+        // development aid (FCGPU_TIMELINE=file): per wave of the last k_extend launch {start, end (100 MHz
+        // ticks), rays, rounds, node steps sum / lane max, primitive tests sum / lane max}; nullptr in normal operation
+        unsigned long long* timeline;
         uint32_t capacity;
     };
 }

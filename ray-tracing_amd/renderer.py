@@ -28,10 +28,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("FCGPU_LIBRARY", LIB_PATH)  # development override: A/B runs of two builds
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     P = C.POINTER
     vp, i32, u32, u64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64
     protos = {

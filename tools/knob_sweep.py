@@ -1,0 +1,13 @@
+"""Runs the A/B child of ab_perf.py under several environment settings (development tool).
+usage: python tools/knob_sweep.py "A=1 B=2" "A=3" ...   (each argument = one configuration; "" = defaults)"""
+import os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ab_perf
+for cfg in sys.argv[1:]:
+    env = dict(os.environ)
+    for kv in cfg.split():
+        k, v = kv.split("=", 1)
+        env[k] = v
+    out = subprocess.run([sys.executable, "-c", ab_perf.CHILD, "8", "64"], env=env, capture_output=True, text=True, timeout=300)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    print(f"[{cfg}]", line[0] if line else "FAILED " + out.stderr[-300:], flush=True)
