@@ -190,7 +190,7 @@ namespace
         int rc;
         if((rc = col(&Q.ray_c0)) || (rc = col(&Q.ray_c1))) return rc;
         if((rc = col(&Q.sh_c0)) || (rc = col(&Q.sh_c1)) || (rc = col(&Q.sh_c2))) return rc;
-        if((rc = col(&Q.hit_c0)) || (rc = col(&Q.hit_c1))) return rc;
+        if((rc = col(&Q.hit_c0)) || (rc = col(&Q.hit_c1)) || (rc = col(&Q.li_shadow))) return rc;
         void* p = nullptr;
         HIP_TRY(c, hipMalloc(&p, static_cast<size_t>(cap)));
         c->queue_allocs.push_back(p);
@@ -258,6 +258,7 @@ namespace
         B.x0 = tile.x0;
         B.y0 = tile.y0;
         B.tw = tile.w;
+        B.div_tw = make_fastdiv(static_cast<uint32_t>(tile.w));
         B.seed = c->seed;
         B.max_len = max_len;
         B.integrator = integrator;
@@ -271,6 +272,7 @@ namespace
         {
             B.pix0 = pix0;
             B.npix = npix;
+            B.div_npix = make_fastdiv(npix);
             B.s0 = s0;
             B.nsamp = nsamp;
             B.parity = 0;

@@ -11,6 +11,7 @@ namespace fcg
     {
         int32_t x0, y0, tw;          // tile origin and width
         uint32_t pix0, npix;         // pixel-in-tile range of this batch
+        FastDiv div_npix, div_tw;    // slot -> (sample, pixel) and pixel -> (row, column)
         uint32_t s0, nsamp;          // sample range of this batch; slots = npix * nsamp
         uint64_t seed;
         int32_t h;                   // hit index being produced / shaded: 1 = camera ray's hit

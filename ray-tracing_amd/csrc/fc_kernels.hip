@@ -36,9 +36,9 @@ namespace fcg
 
     FC_D void slot_to_pixel(const Batch& B, uint32_t slot, uint32_t& px, uint32_t& py, uint32_t& sample)
     {
-        uint32_t sl = slot / B.npix;
+        uint32_t sl = fast_div(slot, B.div_npix);
         uint32_t pit = B.pix0 + (slot - sl * B.npix);
-        uint32_t row = pit / static_cast<uint32_t>(B.tw);
+        uint32_t row = fast_div(pit, B.div_tw);
         px = static_cast<uint32_t>(B.x0) + (pit - row * static_cast<uint32_t>(B.tw));
         py = static_cast<uint32_t>(B.y0) + row;
         sample = B.s0 + sl;
@@ -85,6 +85,39 @@ namespace fcg
         uint32_t slot = key >= 0 ? lds[key][wave] + prefix : INVALID_U32;
         __syncthreads();
         return slot;
+    }
+
+    // Two independent appends (flag a -> queue 0, flag b -> queue 1) in one pass: two barriers and
+    // two atomics per block instead of six barriers.
+    FC_D void block_append2(bool a, bool b, uint32_t* const* counters, uint32_t (*lds)[WAVES], uint32_t& slot_a, uint32_t& slot_b)
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint64_t lt = (1ull << lane) - 1ull;
+        const uint64_t ma = __ballot(a), mb = __ballot(b);
+        if(lane == 0)
+        {
+            lds[0][wave] = __popcll(ma);
+            lds[1][wave] = __popcll(mb);
+        }
+        __syncthreads();
+        if(threadIdx.x < 2)
+        {
+            uint32_t total = 0;
+#pragma unroll
+            for(int w = 0; w < WAVES; ++w) total += lds[threadIdx.x][w];
+            uint32_t base = total ? atomicAdd(counters[threadIdx.x], total) : 0u;
+#pragma unroll
+            for(int w = 0; w < WAVES; ++w)
+            {
+                uint32_t c = lds[threadIdx.x][w];
+                lds[threadIdx.x][w] = base;
+                base += c;
+            }
+        }
+        __syncthreads();
+        slot_a = lds[0][wave] + __popcll(ma & lt);
+        slot_b = lds[1][wave] + __popcll(mb & lt);
+        __syncthreads();  // lds is reused by the next trip
     }
 
     FC_D void wave_stat_add(unsigned long long* stats, int index, uint32_t v)
@@ -162,6 +195,7 @@ namespace fcg
             st.p1[0] = origin.x; st.p1[1] = origin.y; st.p1[2] = origin.z;
             st.w[0] = wi.x; st.w[1] = wi.y; st.w[2] = wi.z;
             Q.state[i] = st;
+            Q.li_shadow[i] = Vec4<R>{R(0), R(0), R(0), R(0)};
 
             Vec4<R> c0{o.x, o.y, o.z, wi.x};
             Vec4<R> c1{wi.y, wi.z, R(0), R(0)};
@@ -302,7 +336,7 @@ namespace fcg
                             h0 = Vec4<R>{p.x, p.y, p.z, T.b0};
                             h1.x = T.b1;
                             h1.y = pack_word(R(0), ms);
-                            pack_ids(h1, prim | (lobe << 30), path);
+                            pack_ids(h1, hit_word(T.pk, lobe), path);
                         }
                         else if(S.env_kind != FCGPU_ENV_NONE)
                         {
@@ -448,18 +482,16 @@ namespace fcg
     };
 
     template<typename R>
-    FC_D SurfacePoint<R> make_surface_point(const SceneDev<R>& S, uint32_t prim, vec3<R> p, R b0, R b1)
+    FC_D SurfacePoint<R> make_surface_point(const SceneDev<R>& S, uint32_t kind, uint32_t idx, vec3<R> p, R b0, R b1)
     {
         SurfacePoint<R> sp;
         sp.p = p;
-        const PrimInfo pi = S.prim_info[prim];
-        sp.entity = pi.entity;
-        sp.kind_index = pi.kind_index;
-        const uint32_t kind = pi.kind_index >> 30, idx = pi.kind_index & 0x3FFFFFFFu;
+        sp.kind_index = (kind << 30) | idx;
         if(kind == KIND_TRI)
         {
             // mesh_surface.hpp:211-248
-            const TriRec& T = S.tris[idx];
+            const TriRec T = S.tris[idx];
+            sp.entity = T.entity;
             vec3<R> p0 = ldv<R>(T.v0), p1 = ldv<R>(T.v1), p2 = ldv<R>(T.v2);
             vec3<R> dp02 = p0 - p2, dp12 = p1 - p2;
             sp.f.ng = normalize(cross(dp02, dp12));
@@ -478,7 +510,7 @@ namespace fcg
                 R d12x = R(A.uv1[0]) - R(A.uv2[0]), d12y = R(A.uv1[1]) - R(A.uv2[1]);
                 R det = d02x * d12y - d02y * d12x;
                 dpdu = (d12y * dp02 - d02y * dp12) / det;
-                if(S.entities[pi.entity].flags & 1u)
+                if(S.entities[T.entity].flags & 1u)
                     sp.f.ns = normalize(b0 * ldv<R>(A.n0) + b1 * ldv<R>(A.n1) + b2 * ldv<R>(A.n2));
                 else
                     sp.f.ns = sp.f.ng;
@@ -490,6 +522,7 @@ namespace fcg
         else
         {
             const XPrim<R>& P = S.xprims[idx];
+            sp.entity = P.entity;
             if(kind == KIND_SPHERE)
             {
                 // sphere_surface.hpp:123-140; tangent (-sin phi, 0, cos phi), phi = atan2(z, x), is
@@ -589,15 +622,15 @@ namespace fcg
             {
                 const uint32_t hi = hit_idx[i];
                 Vec4<R> h0 = Q.hit_c0[hi], h1 = Q.hit_c1[hi];
-                uint32_t prim_lobe, path;
-                unpack_ids(h1, prim_lobe, path);
+                uint32_t hw, path;  // hw = hit_word(kind | index, lobe)
+                unpack_ids(h1, hw, path);
                 uint32_t ms = unpack_word(h1.y);
                 PathState<R> st = Q.state[path];
                 vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
                 vec3<R> Li{st.Li[0], st.Li[1], st.Li[2]};
                 const vec3<R> p1{st.p1[0], st.p1[1], st.p1[2]};
                 const vec3<R> w12{st.w[0], st.w[1], st.w[2]};  // direction that reached this hit
-                SurfacePoint<R> sp = make_surface_point(S, prim_lobe & 0x3FFFFFFFu, vec3<R>{h0.x, h0.y, h0.z}, h0.w, h1.x);
+                SurfacePoint<R> sp = make_surface_point(S, hit_word_kind(hw), hit_word_index(hw), vec3<R>{h0.x, h0.y, h0.z}, h0.w, h1.x);
                 const EntityRec ent = S.entities[sp.entity];
                 const vec3<R> ng = sp.f.ng;
                 const uint32_t above = ms_above(ms), below = ms_below(ms);
@@ -637,7 +670,7 @@ namespace fcg
                     // ---- scatter at p1 := sp.p (forward_mis_integrator.hpp:47-112 / :153-168)
                     const vec3<R> w10 = -w12;
                     const MaterialRec mat = S.materials[ent.material];
-                    const LobeRec<R> L = S.lobes[mat.first_lobe + (prim_lobe >> 30)];
+                    const LobeRec<R> L = S.lobes[mat.first_lobe + hit_word_lobe(hw)];
                     const R eta_a = S.media[above].ior, eta_b = S.media[below].ior;
                     const uint64_t key = slot_key(B, path);
                     constexpr bool DELTA = KEY == L_SPEC_REFL || KEY == L_SPEC_GLASS || KEY == L_SPEC_TRANS;
@@ -744,8 +777,8 @@ namespace fcg
             if constexpr(KEY != Q_FINAL)
             {
                 // two independent appends share one pass: queue 0 = extension rays, queue 1 = shadow rays
-                uint32_t slot_r = block_append<1>(emit_ray ? 0 : -1, q_ctr, q_lds);
-                uint32_t slot_s = block_append<1>(emit_shadow ? 0 : -1, q_ctr + 1, q_lds + 1);
+                uint32_t slot_r, slot_s;
+                block_append2(emit_ray, emit_shadow, q_ctr, q_lds, slot_r, slot_s);
                 if(emit_ray)
                 {
                     Q.ray_c0[slot_r] = r0;
@@ -826,10 +859,11 @@ namespace fcg
                     {
                         // unoccluded: the light-strategy term of forward_mis_integrator.hpp:84-91
                         Vec4<R> c2 = Q.sh_c2[slot];
-                        PathState<R>& st = Q.state[path];
-                        st.Li[0] += c2.x;
-                        st.Li[1] += c2.y;
-                        st.Li[2] += c2.z;
+                        Vec4<R> acc = Q.li_shadow[path];
+                        acc.x += c2.x;
+                        acc.y += c2.y;
+                        acc.z += c2.z;
+                        Q.li_shadow[path] = acc;
                     }
                     slot = INVALID_U32;
                 }
@@ -863,7 +897,7 @@ namespace fcg
         for(uint32_t pp = blockIdx.x * BLOCK + threadIdx.x; pp < B.npix; pp += gridDim.x * BLOCK)
         {
             uint32_t pit = B.pix0 + pp;
-            uint32_t row = pit / static_cast<uint32_t>(B.tw);
+            uint32_t row = fast_div(pit, B.div_tw);
             uint32_t px = static_cast<uint32_t>(B.x0) + (pit - row * static_cast<uint32_t>(B.tw));
             uint32_t py = static_cast<uint32_t>(B.y0) + row;
             double* out = B.film + 3ull * (static_cast<uint64_t>(py) * static_cast<uint64_t>(B.W) + px);
@@ -871,7 +905,8 @@ namespace fcg
             for(uint32_t sl = 0; sl < B.nsamp; ++sl)
             {
                 const PathState<R>& st = Q.state[sl * B.npix + pp];
-                R x = st.Li[0], y = st.Li[1], z = st.Li[2];
+                const Vec4<R> sh = Q.li_shadow[sl * B.npix + pp];
+                R x = st.Li[0] + sh.x, y = st.Li[1] + sh.y, z = st.Li[2] + sh.z;
                 if(!r_isfinite(x) || !r_isfinite(y) || !r_isfinite(z))  // perspective_camera.hpp:126-131
                 {
                     n_nan += 1;

@@ -209,6 +209,41 @@ namespace fcg
         b = static_cast<uint32_t>(u);
     }
 
+    // Division of any 32-bit n by a launch-invariant d (1 <= d < 2^31) with a multiply-high instead of
+    // the ~35-instruction software divide: q = floor(n * M / 2^(32+s)), M = ceil(2^(32+s) / d),
+    // s = ceil(log2 d) (Granlund & Montgomery 1994); mul holds M - 2^32.
+    struct FastDiv
+    {
+        uint32_t d, mul, sh1;  // sh1 = s - 1 (d > 1)
+    };
+    inline FastDiv make_fastdiv(uint32_t d)
+    {
+        FastDiv f{d, 0u, 0u};
+        if(d <= 1u) return f;
+        uint32_t s = 0;
+        while((1ull << s) < d) ++s;
+        const uint64_t m = ((1ull << (32 + s)) + d - 1) / d;
+        f.mul = static_cast<uint32_t>(m - (1ull << 32));
+        f.sh1 = s - 1u;
+        return f;
+    }
+    FC_HD uint32_t fast_div(uint32_t n, const FastDiv& f)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t t = __umulhi(n, f.mul);
+#else
+        const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(n) * f.mul) >> 32);
+#endif
+        const uint32_t q = (t + ((n - t) >> 1)) >> f.sh1;
+        return f.d <= 1u ? n : q;
+    }
+
+    // hit-queue word: lobe index within the material (2) | primitive kind (2) | index into tris / xprims (28)
+    FC_HD uint32_t hit_word(uint32_t pk, uint32_t lobe) { return (lobe << 30) | ((pk >> 30) << 28) | (pk & 0x0FFFFFFFu); }
+    FC_HD uint32_t hit_word_lobe(uint32_t w) { return w >> 30; }
+    FC_HD uint32_t hit_word_kind(uint32_t w) { return (w >> 28) & 3u; }
+    FC_HD uint32_t hit_word_index(uint32_t w) { return w & 0x0FFFFFFFu; }
+
     // one 32-bit word in a single R slot
     FC_HD float pack_word(float, uint32_t a) { return __builtin_bit_cast(float, a); }
     FC_HD double pack_word(double, uint32_t a) { return __builtin_bit_cast(double, static_cast<uint64_t>(a)); }
@@ -277,6 +312,10 @@ namespace fcg
         Vec4<R>* sh_c1;
         Vec4<R>* sh_c2;
         PathState<R>* state;
+        // light-strategy radiance by path id, kept apart from the path state: the shadow kernel is its
+        // only writer (16 B read-modify-write per visible ray instead of a 64-B state line) and
+        // accumulate adds it to state.Li
+        Vec4<R>* li_shadow;
         QueueCounters* counters;
         unsigned long long* stats;
         // development aid (FCGPU_TIMELINE=file): per wave of the last k_extend launch {start, end (100 MHz

@@ -1,4 +1,5 @@
 """Host-side logic that needs no GPU: scene descriptions, tile sharding, sampler statistics."""
+import os
 import numpy as np
 
 from common import A, R, S
@@ -59,3 +60,13 @@ def test_oracle_tile_invariance():
     a, _, _ = o.render(1, seed=1, sample_begin=0)
     b, _, _ = o.render(1, seed=1, sample_begin=1)
     assert np.allclose(a + b, full, rtol=1e-14)
+
+
+def test_fast_div_matches_hardware_divide(tmp_path):
+    """csrc/fc_types.h fast_div (slot -> pixel mapping on the device) against n / d on the CPU."""
+    import subprocess
+    exe = tmp_path / "test_fastdiv"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_fastdiv.cpp")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-o", str(exe), src], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout

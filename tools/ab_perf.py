@@ -33,7 +33,7 @@ print("RESULT %%.1f Msamples/s %%.3f Grays/s | " %% (1920*1080*spp/dt/1e6, rays/
 def main():
     # usage: ab_perf.py [--reps N] [--spp N] [--tess N] LIB...
     args = sys.argv[1:]
-    opt = {"--reps": "2", "--spp": "8", "--tess": "64"}
+    opt = {"--reps": "2", "--spp": "16", "--tess": "64"}
     libs = []
     while args:
         a = args.pop(0)
