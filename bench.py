@@ -2,8 +2,8 @@
 """Headline benchmark: room scene, Forward MIS, 1920x1080 (BASELINE.json configs[1]).
 
 A "step" renders `--spp-per-step` samples per pixel of the full frame through the HIP wavefront
-path (generate -> {extend, shade<lobe>, shadow} x 10 -> accumulate); the default 16 steps x 64
-spp are the whole 1024-spp job. All inputs (scene, BVH, queues) are resident in HBM before the
+path (generate -> {extend, sort, shade<lobe>, shadow} x 10 -> accumulate), in batches of 2^25 paths
+(16 spp); the default 16 steps x 64 spp are the whole 1024-spp job. All inputs (scene, BVH, queues) are resident in HBM before the
 timed region starts; the film stays on the device (read-back is outside the timed region for
 N = 1, the RCCL film reduce is inside it for N > 1).
 
@@ -27,6 +27,11 @@ sys.path.insert(0, ROOT)
 PIPELINE_BYTES_PER_RAY = 112.0  # 32 ray in + 16 hit out + 64 path-state share
 EXTEND_BYTES_PER_RAY = 48.0     # the extend kernel's own share of it (ray record in, hit record out)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# Fabric traffic of k_extend per ray, from the rocprofv3 PMC passes kept under profiles/
+# (r01_pmc_v4_tcc_*.txt: TCC_EA0_RDREQ all 128-byte requests, TCC_EA0_WRREQ split 64/32 bytes; this is
+# what FETCH_SIZE doubled + WRITE_SIZE give on gfx950): (1.85e8*128 + 2.34e8*64 + 1.42e8*32) B over
+# 3.52e8 rays. Counted at the L2's memory side, i.e. Infinity-Cache hits included.
+EXTEND_TRAFFIC_BYTES_PER_RAY = 123.0
 
 
 def cpu_baseline(S, A, args):
@@ -157,7 +162,10 @@ def main():
             achieved = EXTEND_BYTES_PER_RAY * rays_per_launch / avg_s / 1e9
             out["roofline"] = {
                 "kernel": "k_extend<float>" if args.precision == "f32" else "k_extend<double>", "bound": "hbm",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": EXTEND_TRAFFIC_BYTES_PER_RAY * rays_per_launch if args.precision == "f32" else None,
+                "traffic_note": "bytes per launch = 123 B/ray (PMC, profiles/r01_pmc_v4_tcc_*.txt) x rays per launch; the kernel is "
+                                "VALU/latency bound (VALU busy 82 %, lane utilisation 0.56: profiles/r01_pmc_v4_sq.txt), not HBM bound",
                 "avg_launch_us": avg_s * 1e6, "launches": int(launches), "rays_per_launch": rays_per_launch,
                 "algorithmic_bytes_per_ray": EXTEND_BYTES_PER_RAY,
                 "stage_ms": {k: v[0] for k, v in stages.items()},

@@ -192,6 +192,7 @@ typedef struct fcgpu_counters {
 #define FCGPU_STAGE_SHADE 2
 #define FCGPU_STAGE_SHADOW 3
 #define FCGPU_STAGE_ACCUMULATE 4
+#define FCGPU_STAGE_SORT 5      /* material sort of the hit queue (k_sort), between extend and shade */
 #define FCGPU_STAGE_COUNT 8
 typedef struct fcgpu_stage_times {
     double ms[FCGPU_STAGE_COUNT];        /* summed device milliseconds per stage */

@@ -102,7 +102,7 @@ class StageTimes(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
 
 
-STAGE_NAMES = ["generate", "extend", "shade", "shadow", "accumulate"]
+STAGE_NAMES = ["generate", "extend", "shade", "shadow", "accumulate", "sort"]
 
 # numpy dtypes with the same layout as Ray / Hit (for bulk ray sets)
 import numpy as _np

@@ -295,7 +295,11 @@ namespace
                     StageSpan sp{c, FCGPU_STAGE_EXTEND};
                     launch_extend(L, S, Q, B);
                 }
-                c->launches += 1;
+                {
+                    StageSpan sp{c, FCGPU_STAGE_SORT};
+                    launch_sort(L, Q, B);
+                }
+                c->launches += 2;
                 {
                     StageSpan sp{c, FCGPU_STAGE_SHADE};
                     if(h < max_len)

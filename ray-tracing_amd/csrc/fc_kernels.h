@@ -34,6 +34,7 @@ namespace fcg
 
     template<typename R> void launch_generate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);
     template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);
+    template<typename R> void launch_sort(const LaunchCfg& L, const Wavefront<R>& Q, const Batch& B);
     // key in [0, L_COUNT): lobe shade; Q_FINAL: last vertex; Q_MISS: environment term
     template<typename R> void launch_shade(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key);
     template<typename R> void launch_shadow(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);

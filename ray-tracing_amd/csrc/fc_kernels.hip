@@ -999,6 +999,9 @@ namespace fcg
             hipLaunchKernelGGL((k_extend<R, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
         else
             hipLaunchKernelGGL((k_extend<R, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
+    }
+    template<typename R> void launch_sort(const LaunchCfg& L, const Wavefront<R>& Q, const Batch& B)
+    {
         hipLaunchKernelGGL(k_sort<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, Q, B);
     }
     template<typename R> void launch_shade(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key)
@@ -1039,6 +1042,7 @@ namespace fcg
 #define FCG_INSTANTIATE(R)                                                                                             \
     template void launch_generate<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);          \
     template void launch_extend<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);            \
+    template void launch_sort<R>(const LaunchCfg&, const Wavefront<R>&, const Batch&);                                  \
     template void launch_shade<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&, int);        \
     template void launch_shadow<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);            \
     template void launch_accumulate<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);        \
