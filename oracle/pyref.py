@@ -156,3 +156,54 @@ def restatement(precision="f64"):
 def image_from_film(rgb_sum, count):
     """renderer::export_image (renderer.hpp:118-138): sum / total count, as float32."""
     return (rgb_sum / float(count)).astype(np.float32)
+
+
+def reference_load_mesh(root, name):
+    """<root>/assets/<name>.mesh read by the REFERENCE's own loader (fc::assets::get_mesh,
+    src/core/assets.cpp:105-160) -> dict(positions, indices, normals | None, uvs | None)."""
+    lib = reference().lib
+    f = lib.fcref_load_mesh
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    nv, ni, hn, hu = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_int()
+    args = [os.fsencode(root), name.encode()]
+    if f(*args, nv, ni, hn, hu, None, None, None, None) != 0:
+        raise RuntimeError("reference loader rejected the mesh")
+    pos = np.zeros((nv.value, 3), np.float32)
+    nrm = np.zeros((nv.value, 3), np.float32) if hn.value else None
+    uv = np.zeros((nv.value, 2), np.float32) if hu.value else None
+    idx = np.zeros(ni.value, np.uint32)
+    f(*args, nv, ni, hn, hu, pos.ctypes.data, nrm.ctypes.data if hn.value else None, uv.ctypes.data if hu.value else None, idx.ctypes.data)
+    return {"positions": pos, "indices": idx, "normals": nrm, "uvs": uv}
+
+
+def reference_decode_image(raw, fmt):
+    """Raw .asset pixels (height, width, channels) decoded by the REFERENCE's pixel classes
+    (image::rgb per texel, src/images/*.hpp) -> (h, w, 3) doubles."""
+    lib = reference().lib
+    f = lib.fcref_decode_image
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    raw = np.ascontiguousarray(raw)
+    h, w = raw.shape[:2]
+    out = np.zeros((h, w, 3), np.float64)
+    if f(["r8", "rgb8", "srgb8", "rgb32"].index(fmt), w, h, raw.ctypes.data, out.ctypes.data) != 0:
+        raise RuntimeError("unknown image format")
+    return out
+
+
+def reference_load_image(root, name):
+    """fc::assets::get_image on <root>/assets/images/<name>; returns None when the reference's loader
+    rejects the file -- which the g++ build always does (see fcref_load_image in ref_harness.cpp)."""
+    lib = reference().lib
+    f = lib.fcref_load_image
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+    w, h = C.c_int(), C.c_int()
+    args = [os.fsencode(root), name.encode()]
+    if f(*args, w, h, None) != 0:
+        return None
+    out = np.zeros((h.value, w.value, 3), np.float64)
+    f(*args, w, h, out.ctypes.data)
+    return out

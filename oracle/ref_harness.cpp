@@ -25,6 +25,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -33,6 +34,12 @@
 #include <vector>
 
 #include "core/math.hpp"
+#include "core/assets.hpp"
+#include "images/r8_image.hpp"
+#include "images/rgb8_image.hpp"
+#include "images/rgb32_image.hpp"
+#include "images/srgb8_image.hpp"
+#include <filesystem>
 #define explicit
 #include "core/frame.hpp"
 #undef explicit
@@ -641,4 +648,112 @@ extern "C"
     }
 
     std::uint64_t fcref_ray_record_size() { return sizeof(ray_record); }
+
+    // ---- the reference's own asset loader (src/core/assets.cpp, compiled where it lies): reads
+    // <root>/assets/<name>.mesh and <root>/assets/images/<name>.{metadata,asset}. fc::assets resolves
+    // paths against the current directory, so these calls change it for their duration (tests only).
+    // Pass null arrays to query the counts first. Returns 0, or -1 when the loader rejects the file
+    // (it terminates on a bad file: `throw;` without an active exception, assets.cpp:108 -- the
+    // caller is expected to hand over files that exist).
+    int fcref_load_mesh(char const* root, char const* name, std::uint32_t* vertex_count, std::uint32_t* index_count, int* has_normals,
+                        int* has_uvs, float* positions, float* normals, float* uvs, std::uint32_t* indices)
+    {
+        std::filesystem::path const back{std::filesystem::current_path()};
+        std::filesystem::current_path(root);
+        int rc{0};
+        {
+            fc::assets loader{};
+            std::shared_ptr<fc::mesh> m{loader.get_mesh(name)};
+            if(!m)
+                rc = -1;
+            else
+            {
+                std::uint32_t const nv{m->get_vertex_count()}, ni{m->get_index_count()};
+                *vertex_count = nv;
+                *index_count = ni;
+                *has_normals = m->get_normals() != nullptr;
+                *has_uvs = m->get_uvs() != nullptr;
+                if(positions) std::memcpy(positions, m->get_positions(), sizeof(float) * 3 * nv);
+                if(normals && m->get_normals()) std::memcpy(normals, m->get_normals(), sizeof(float) * 3 * nv);
+                if(uvs && m->get_uvs()) std::memcpy(uvs, m->get_uvs(), sizeof(float) * 2 * nv);
+                if(indices) std::memcpy(indices, m->get_indices(), sizeof(std::uint32_t) * ni);
+            }
+        }
+        std::filesystem::current_path(back);
+        return rc;
+    }
+
+    // Texel decode by the reference's pixel classes (images/*.hpp): the raw bytes of an .asset file
+    // (format 0 r8, 1 rgb8, 2 srgb8, 3 rgb32) are memcpy'd into the reference's pixel vector exactly as
+    // assets::load_image reads them (assets.cpp:205-231), then image::rgb() is taken per texel.
+    int fcref_decode_image(int format, int width, int height, void const* raw, double* rgb)
+    {
+        std::size_t const n{static_cast<std::size_t>(width) * static_cast<std::size_t>(height)};
+        std::shared_ptr<fc::image> img{};
+        auto make{[&]<typename P>() {
+            std::vector<P> pixels{};
+            pixels.resize(n);
+            std::memcpy(reinterpret_cast<char*>(pixels.data()), raw, n * sizeof(P));
+            img = std::shared_ptr<fc::raw_image<P>>{new fc::raw_image<P>{{width, height}, std::move(pixels)}};
+        }};
+        if(format == 0) make.template operator()<fc::r8_pixel>();
+        else if(format == 1) make.template operator()<fc::rgb8_pixel>();
+        else if(format == 2) make.template operator()<fc::srgb8_pixel>();
+        else if(format == 3) make.template operator()<fc::rgb32_pixel>();
+        else return -1;
+        for(int y{0}; y < height; ++y)
+            for(int x{0}; x < width; ++x)
+            {
+                fc::vector3 const c{img->rgb({x, y})};
+                double* o{rgb + 3 * (static_cast<std::size_t>(y) * width + x)};
+                o[0] = c.x;
+                o[1] = c.y;
+                o[2] = c.z;
+            }
+        return 0;
+    }
+
+    // The file path through fc::assets::get_image. NOTE: built with g++ this returns -1 for every
+    // file: assets.cpp:168 brace-initialises a json from the parsed document, which g++ turns into a
+    // one-element ARRAY (an nlohmann/compiler interaction; MSVC copies), and from_json's at("type")
+    // then throws type_error.304. The image file format is therefore pinned by its description in
+    // assets.cpp only; the texel decode is pinned by fcref_decode_image above.
+    int fcref_load_image(char const* root, char const* name, int* width, int* height, double* rgb)
+    {
+        std::filesystem::path const back{std::filesystem::current_path()};
+        std::filesystem::current_path(root);
+        int rc{0};
+        {
+            fc::assets loader{};
+            std::shared_ptr<fc::image> img{};
+            try
+            {
+                img = loader.get_image(name);
+            }
+            catch(std::exception const& e)
+            {
+                std::fprintf(stderr, "fcref_load_image: %s\n", e.what());
+            }
+            if(!img)
+                rc = -1;
+            else
+            {
+                fc::vector2i const res{img->get_resolution()};
+                *width = res.x;
+                *height = res.y;
+                if(rgb)
+                    for(int y{0}; y < res.y; ++y)
+                        for(int x{0}; x < res.x; ++x)
+                        {
+                            fc::vector3 const c{img->rgb({x, y})};
+                            double* o{rgb + 3 * (static_cast<std::size_t>(y) * res.x + x)};
+                            o[0] = c.x;
+                            o[1] = c.y;
+                            o[2] = c.z;
+                        }
+            }
+        }
+        std::filesystem::current_path(back);
+        return rc;
+    }
 }

@@ -1,11 +1,15 @@
 // demo_room.cpp -- C++ host using fcgpu::gpu_renderer exactly where the reference's main() uses
 // fc::renderer (src/main.cpp:3-12 -> src/example_scenes.hpp:187-263): the 10-primitive room
 // (6 wall planes, 1 plane emitter, the reference's three spheres), Forward MIS, writes room.raw.
+// With a 4th argument <root> it is the body of scene_room() proper: `walls`, `lights_1`, `lights_2` are
+// loaded from <root>/assets/*.mesh (the reference's asset format, fc_assets.hpp; write the stand-in
+// meshes with `python -c "import importlib; importlib.import_module('ray-tracing_amd.assets').write_room_assets('<root>')"`).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+#include "fc_assets.hpp"
 #include "fc_renderer.hpp"
 
 int main(int argc, char** argv)
@@ -57,7 +61,40 @@ int main(int argc, char** argv)
         e.emission_strength = strength;
         entities.push_back(e);
     };
+    std::vector<float> positions;
+    std::vector<std::uint32_t> indices;
+    auto mesh = [&](const std::string& root, const char* name)  // mesh_surface{prs_transform{}, assets.get_mesh(name)}, :193
+    {
+        fcgpu::mesh_data m;
+        std::string err;
+        if(!fcgpu::load_mesh(fcgpu::mesh_path(root, name), m, err))
+        {
+            std::fprintf(stderr, "%s\n", err.c_str());
+            std::exit(1);
+        }
+        fcgpu_surface s{};
+        s.kind = FCGPU_SURFACE_MESH;
+        s.scale[0] = s.scale[1] = s.scale[2] = 1;
+        s.vertex_offset = static_cast<std::uint32_t>(positions.size() / 3);
+        s.vertex_count = m.vertex_count();
+        s.index_offset = static_cast<std::uint32_t>(indices.size());
+        s.index_count = static_cast<std::uint32_t>(m.indices.size());
+        positions.insert(positions.end(), m.positions.begin(), m.positions.end());
+        indices.insert(indices.end(), m.indices.begin(), m.indices.end());
+        surfaces.push_back(s);
+        return static_cast<int>(surfaces.size() - 1);
+    };
     int white = material(FCGPU_MATERIAL_DIFFUSE, 0.8, 0.8, 0.8, 0);
+    if(argc > 4)
+    {
+        const std::string root{argv[4]};
+        const int dark = material(FCGPU_MATERIAL_DIFFUSE, 0.1, 0.1, 0.1, 0);
+        entity(mesh(root, "walls"), white, -1, 0);        // example_scenes.hpp:192-197
+        entity(mesh(root, "lights_1"), dark, -1, 0);      // :200-205
+        entity(mesh(root, "lights_2"), dark, -1, 250.0);  // :208-216
+    }
+    else
+    {
     entity(plane(0, 0, 5, 24, 30, 0, 0), white, -1, 0);
     entity(plane(0, 8, 5, 24, 30, pi, 0), white, -1, 0);
     entity(plane(-12, 4, 5, 8, 30, 0, -h), white, -1, 0);
@@ -65,6 +102,7 @@ int main(int argc, char** argv)
     entity(plane(0, 4, -10, 24, 8, h, 0), white, -1, 0);
     entity(plane(0, 4, 20, 24, 8, -h, 0), white, -1, 0);
     entity(plane(0, 7.9, 4, 3, 3, pi, 0), material(FCGPU_MATERIAL_DIFFUSE, 0.1, 0.1, 0.1, 0), -1, 250.0);
+    }
     entity(sphere(4.2, 2.01, 0, 2), material(FCGPU_MATERIAL_DIFFUSE, 0.2, 0.4, 0.8, 0), -1, 0);
     fcgpu_medium med{};
     med.priority = 1; med.ior = 1.45; med.color[0] = 0.6; med.color[1] = 0.2; med.color[2] = 0.8; med.density = 0.5;
@@ -77,6 +115,8 @@ int main(int argc, char** argv)
     d.materials = materials.data(); d.material_count = static_cast<uint32_t>(materials.size());
     d.media = media.data(); d.medium_count = static_cast<uint32_t>(media.size());
     d.entities = entities.data(); d.entity_count = static_cast<uint32_t>(entities.size());
+    d.positions = positions.data(); d.vertex_total = static_cast<uint32_t>(positions.size() / 3);
+    d.indices = indices.data(); d.index_total = static_cast<uint32_t>(indices.size());
     d.camera.position[0] = -7.23; d.camera.position[1] = 2.79; d.camera.position[2] = 16.37;
     d.camera.rotation[0] = -4.641 / 180 * pi; d.camera.rotation[1] = 157.552 / 180 * pi;
     d.camera.fov = 35.0 / 180 * pi;

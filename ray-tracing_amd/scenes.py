@@ -226,7 +226,16 @@ CENTER_MATERIALS = ("rough_glass", "smooth_glass", "diffuse", "plastic", "rough_
                     "smooth_plastic", "standard", "transmission")
 
 
-def room(width=1920, height=1080, tess=64, center="rough_glass", env=None):
+def room_meshes(tess=64):
+    """The three stand-in meshes of the room by their reference asset names -> (positions, indices)."""
+    wp, wi = box_inward(ROOM_LO, ROOM_HI, tess)
+    fixtures = merge([box_outward((x - 0.4, 7.9, z - 0.4), (x + 0.4, 8.0, z + 0.4), faces="xXyzZ")
+                      for x, z in ROOM_LIGHTS])
+    quads = merge([grid_quad((x - 0.25, 7.88, z - 0.25), (0.5, 0, 0), (0, 0, 0.5), 1, 1) for x, z in ROOM_LIGHTS])
+    return {"walls": (wp, wi), "lights_1": fixtures, "lights_2": quads}
+
+
+def room(width=1920, height=1080, tess=64, center="rough_glass", env=None, assets_root=None):
     """Stand-in for example_scenes.hpp:187-263.
 
     Verbatim from the reference: the three spheres (:218-242), their materials, the medium
@@ -236,15 +245,21 @@ def room(width=1920, height=1080, tess=64, center="rough_glass", env=None):
     tess x tess quads (12*tess^2 triangles); `lights_2` = eight 0.5 x 0.5 downward quads at
     y = 7.88; `lights_1` = open fixture boxes (no top face) around them, y in [7.9, 8].
     `center` swaps the middle sphere's material for the material sweep (BASELINE config 3).
+    `assets_root`: load `walls`, `lights_1`, `lights_2` from <assets_root>/assets/*.mesh (the
+    reference's asset format, see assets.py) instead of generating them.
     """
     sc = Scene()
-    wp, wi = box_inward(ROOM_LO, ROOM_HI, tess)
-    walls = sc.mesh(wp, wi)
-    fixtures = merge([box_outward((x - 0.4, 7.9, z - 0.4), (x + 0.4, 8.0, z + 0.4), faces="xXyzZ")
-                      for x, z in ROOM_LIGHTS])
-    lights_1 = sc.mesh(*fixtures)
-    quads = merge([grid_quad((x - 0.25, 7.88, z - 0.25), (0.5, 0, 0), (0, 0, 0.5), 1, 1) for x, z in ROOM_LIGHTS])
-    lights_2 = sc.mesh(*quads)
+    if assets_root is None:
+        meshes = room_meshes(tess)
+    else:
+        from . import assets as AS
+        meshes = {}
+        for name in ("walls", "lights_1", "lights_2"):
+            m = AS.read_mesh(AS.mesh_path(assets_root, name))
+            meshes[name] = (m["positions"], m["indices"])
+    walls = sc.mesh(*meshes["walls"])
+    lights_1 = sc.mesh(*meshes["lights_1"])
+    lights_2 = sc.mesh(*meshes["lights_2"])
 
     sc.entity(walls, sc.diffuse((0.8, 0.8, 0.8)))
     sc.entity(lights_1, sc.diffuse((0.1, 0.1, 0.1)))

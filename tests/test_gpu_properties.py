@@ -141,3 +141,28 @@ def test_empty_and_degenerate_inputs():
         assert hits["prim"][0] == 6 and abs(hits["t"][0] - 3.9) < 1e-5  # the plane emitter at y = 7.9
         assert hits["prim"][1] == 0xFFFFFFFF  # t_max shorter than the wall distance
         assert hits["prim"][2] == 0xFFFFFFFF  # outside the room, pointing away
+
+
+def test_cpp_host_renders_the_room_from_asset_files(tmp_path):
+    """csrc/demo_room (C++ host over the C-ABI, meshes read by fc_assets.hpp from the reference's
+    .mesh format) against the Python host on the generated scene: same library, same scene."""
+    import importlib
+    import os
+    import subprocess
+
+    from common import ROOT, pixel_rel_err
+
+    AS = importlib.import_module("ray-tracing_amd.assets")
+    exe = os.path.join(ROOT, "ray-tracing_amd", "csrc", "build", "demo_room")
+    assert os.path.exists(exe), "build csrc/build/demo_room first (make -C ray-tracing_amd/csrc)"
+    AS.write_room_assets(str(tmp_path), tess=8)
+    w, h, spp = 96, 54, 4
+    out = subprocess.run([exe, str(w), str(h), str(spp), str(tmp_path)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    img = np.fromfile(tmp_path / "room.raw", dtype=np.float32).reshape(h, w, 3)
+    rgb, n, _ = render(S.room(w, h, tess=8, assets_root=str(tmp_path)), spp=spp)
+    ref = (rgb / n).reshape(h, w, 3)
+    # the two hosts build the camera angles with differently rounded degree->radian products, so a
+    # few paths may flip a discrete decision: compare like the fp32 parity tests do
+    err = pixel_rel_err(img.astype(np.float64), ref)
+    assert np.mean(err < 1e-3) > 0.97 and abs(img.mean() - ref.mean()) < 0.01 * ref.mean()
