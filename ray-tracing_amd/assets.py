@@ -9,7 +9,7 @@ srgb8 | rgb32) + `<name>.asset` (raw pixels, row-major, top row first; assets.cp
 
 The reference repository does not ship its assets (assets/ is git-ignored); `write_room_assets`
 writes the stand-in meshes of scenes.room in this format so that the unmodified reference loader
-(`fc::assets`) can read them -- tests/test_assets.py checks exactly that through oracle/_ref.
+(`fc::assets`) can read them -- tests/test_assets.py checks exactly that against the compiled reference.
 """
 import json
 import os
