@@ -219,6 +219,14 @@ int fcgpu_upload_scene(fcgpu_ctx* ctx, const fcgpu_scene_desc* scene);
  * the counter-based stream is keyed by (seed, pixel x, pixel y, sample index, dimension).   */
 int fcgpu_set_sampler(fcgpu_ctx* ctx, uint64_t seed);
 
+/* Replaces stratified_sampler{sample_count, seed} (stratified_sampler.hpp:12-19, 94-150), the sampler
+ * every example scene uses (example_scenes.hpp:90,176,252,305,351): per pixel and dimension the
+ * floor(sqrt(sample_count))^2 samples are jittered points of a square grid in shuffled order
+ * (fcgpu_sampler.h, FCGPU_SAMPLER_STRATIFIED). Statistical, not bitwise, equivalence with the
+ * reference's pcg32-driven tables. Sample indices beyond the grid start a new grid.
+ * FCGPU_E_INVALID when sample_count is 0 or above 2^24.                                         */
+int fcgpu_set_sampler_stratified(fcgpu_ctx* ctx, uint64_t seed, uint32_t sample_count);
+
 /* Replaces the pixel x sample loop of renderer::worker_thread (renderer.hpp:154-179) calling
  * integrator::run_once (integrator.hpp:18) for every pixel of `tile` and every sample index in
  * [sample_begin, sample_begin + sample_count). Asynchronous; ordered on the context's stream. */

@@ -11,6 +11,9 @@
 
 namespace fco
 {
+    // 0 = random stream; else stratified_sampler{count, seed} analogue (fcgpu_sampler.h); set through *_set_stratified
+    static uint32_t g_stratified_count = 0;
+
     namespace
     {
         constexpr double PI = 3.141592653589793;  // math.hpp:13
@@ -1226,22 +1229,24 @@ namespace fco
         explicit Tracer(const Scene<R>& s) : S{s} {}
 
         // counter-based sampler behind the fc::sampler protocol (sampler.hpp:15-24)
-        uint64_t key{};
+        fcgpu_sampler_config sampler{fcgpu_sampler_random(0)};
+        fcgpu_sample_stream stream{};
         uint32_t dim{};
-        void set_sample(uint64_t seed, int px, int py, uint32_t sample)
+        void set_sample(const fcgpu_sampler_config& cfg, int px, int py, uint32_t sample)
         {
-            key = fcgpu_sample_key(seed, static_cast<uint32_t>(px), static_cast<uint32_t>(py), sample);
+            sampler = cfg;
+            stream = fcgpu_stream_begin(&sampler, static_cast<uint32_t>(px), static_cast<uint32_t>(py), sample);
             dim = 0;
         }
         void get(R& x, R& y)
         {
-            uint64_t bits = fcgpu_sample_bits(key, dim++);
+            uint64_t bits = fcgpu_stream_bits(&sampler, stream, dim++);
             x = R(fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE);
             y = R(fcgpu_sample_y24(bits) * FCGPU_SAMPLER_SCALE);
         }
         double get_x_double()
         {
-            uint64_t bits = fcgpu_sample_bits(key, dim++);
+            uint64_t bits = fcgpu_stream_bits(&sampler, stream, dim++);
             return fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
         }
         void advance(int n) { dim += static_cast<uint32_t>(n); }
@@ -1590,6 +1595,7 @@ namespace fco
     {
         const Scene<R>& S = *static_cast<Handle<R>*>(handle)->scene;
         const bool mis = integrator == FCGPU_INTEGRATOR_MIS;
+        const fcgpu_sampler_config sampler_cfg = g_stratified_count ? fcgpu_sampler_stratified(seed, g_stratified_count) : fcgpu_sampler_random(seed);
         if(ray_log) threads = 1;
         threads = std::max(1, threads);
         const int W = S.cam.width, H = S.cam.height;
@@ -1611,7 +1617,7 @@ namespace fco
                 double acc[3]{0, 0, 0};
                 for(uint32_t s = 0; s < sample_count; ++s)
                 {
-                    tr.set_sample(seed, px, py, sample_begin + s);
+                    tr.set_sample(sampler_cfg, px, py, sample_begin + s);
                     V3<R> Li = tr.run_once(mis, max_path_length, visible_inf != 0, px, py);
                     // beta0 = W*H (perspective_camera.hpp:64-68) then the NaN/Inf guard (:126-131)
                     double v[3]{static_cast<double>(Li.x) * W * H, static_cast<double>(Li.y) * W * H, static_cast<double>(Li.z) * W * H};
@@ -1749,6 +1755,7 @@ namespace fco
     extern "C" void* PREFIX##_scene_create(const fcgpu_scene_desc* d) { return fco::scene_create<R>(d); }                                          \
     extern "C" void PREFIX##_scene_destroy(void* h) { delete static_cast<fco::Handle<R>*>(h); }                                                    \
     extern "C" void PREFIX##_set_epsilon(void* h, double e) { static_cast<fco::Handle<R>*>(h)->scene->epsilon = static_cast<R>(e); }               \
+    extern "C" void PREFIX##_set_stratified(uint32_t count) { fco::g_stratified_count = count; }                                                  \
     extern "C" int PREFIX##_render(void* h, int integ, int mpl, int vis, uint64_t seed, uint32_t sb, uint32_t sc, int x0, int y0, int w, int hh,     \
                                    int threads, double* rgb, uint64_t* cnt, fco::Stats* st, fco::RayRecord* log, uint64_t cap, uint64_t* nlog)       \
     {                                                                                                                                             \

@@ -31,6 +31,14 @@ FILMS = [
     ("nested_noenv", "nested_media", dict(width=32, height=32, smooth=True, env=None), 4, 10),
 ] + [("sweep_" + c, "room", dict(width=40, height=24, tess=2, center=c), 4, 10) for c in S.CENTER_MATERIALS]
 
+# stratified mode of include/fcgpu_sampler.h (the stream is ours, the integrators consuming it are the
+# reference's): (name, builder, kwargs, spp rendered, max_path_length, stratified sample count).
+# zoo_strat16_epoch renders 20 samples over a 16-sample grid, so sample indices 16..19 start a second grid.
+FILMS_STRATIFIED = [
+    ("room_t4_strat9", "room", dict(width=64, height=36, tess=4), 9, 10, 9),
+    ("zoo_strat16_epoch", "primitives_zoo", dict(width=40, height=40), 20, 10, 16),
+]
+
 
 def random_rays(n, lo, hi, seed):
     rng = np.random.default_rng(seed)
@@ -65,23 +73,29 @@ def main():
     ref = pyref.reference()
     meta = dict(generator="full-confession/ray-tracing compiled with g++ -O2 -fpermissive (right-to-left argument evaluation)")
 
-    for name, builder, kw, spp, mpl in FILMS:
+    only = sys.argv[1:]  # optional: fixture-name substrings to (re)generate; default everything
+    wanted = lambda n: not only or any(o in n for o in only)
+    for name, builder, kw, spp, mpl, strat in [f + (0,) for f in FILMS] + FILMS_STRATIFIED:
+        if not wanted("film_" + name):
+            continue
         sc = S.BUILDERS[builder](**kw)
         rs = ref.scene(sc)
         out = {}
         for integ, tag in ((A.INTEGRATOR_MIS, "mis"), (A.INTEGRATOR_BSDF, "bsdf")):
-            rgb, n, st = rs.render(spp, integrator=integ, max_path_length=mpl, threads=8, seed=7)
+            rgb, n, st = rs.render(spp, integrator=integ, max_path_length=mpl, threads=8, seed=7, stratified=strat or None)
             out[tag + "_rgb_sum"] = rgb
             out[tag + "_count"] = np.uint64(n)
             out[tag + "_rays"] = np.array([st.closest_rays, st.any_rays, st.any_occluded, st.nan_samples], np.uint64)
         np.savez_compressed(os.path.join(OUT, f"film_{name}.npz"), builder=builder, kwargs=repr(kw), spp=spp, max_path_length=mpl,
-                            seed=7, **meta, **out)
+                            seed=7, stratified=strat, **meta, **out)
         print("film", name, {k: float(v.mean()) for k, v in out.items() if k.endswith("rgb_sum")})
         rs.close()
 
     # ray / hit sets: the rays the reference itself casts (natural distribution) + uniform random rays
     for name, builder, kw, lo, hi in (("room_t6", "room", dict(width=32, height=18, tess=6), [-11.5, 0.2, -9.5], [11.5, 7.8, 19.5]),
                                       ("zoo", "primitives_zoo", dict(width=24, height=24), [-6, 0.1, -5], [6, 6, 8])):
+        if not wanted("rays_" + name):
+            continue
         sc = S.BUILDERS[builder](**kw)
         rs = ref.scene(sc)
         _, _, _, log = rs.render(2, threads=1, seed=3, record_rays=200000)
@@ -111,6 +125,8 @@ def main():
         print("rays", name, len(allrays), "bvh/brute prim mismatches", int((closest["prim"] != brute["prim"]).sum()))
         rs.close()
 
+    if not (wanted("bsdf_tables") and wanted("sampler_kat")):
+        return
     # per-lobe tables: bsdf::evaluate / pdf_wi / sample_wi through material::evaluate
     mats = {
         "diffuse": A.Material(kind=A.MATERIAL_DIFFUSE),

@@ -106,8 +106,13 @@ class _Scene:
             pass
 
     def render(self, spp, integrator=A.INTEGRATOR_MIS, max_path_length=10, visible_env=True, seed=0, sample_begin=0,
-               tile=None, threads=1, record_rays=0):
-        """Returns (rgb_sum[H,W,3] f64, sample_count, Stats[, ray log])."""
+               tile=None, threads=1, record_rays=0, stratified=None):
+        """Returns (rgb_sum[H,W,3] f64, sample_count, Stats[, ray log]).
+        `stratified=n`: the stratified mode of fcgpu_sampler.h over n samples (default: random stream)."""
+        f = self.b._fn("_set_stratified")
+        f.argtypes = [C.c_uint32]
+        f.restype = None
+        f(int(stratified or 0))
         W, H = self.width, self.height
         x0, y0, w, h = tile if tile is not None else (0, 0, W, H)
         rgb = np.zeros((H, W, 3), np.float64)

@@ -73,25 +73,28 @@ namespace
     using namespace fc;
 
     // ---------------------------------------------------------------- sampler
+    // 0 = random stream; else the stratified mode of fcgpu_sampler.h over that many samples (fcref_set_stratified)
+    std::uint32_t g_stratified_count{0};
+
     class counter_sampler : public sampler_source
     {
     public:
-        counter_sampler(int sample_count, std::uint64_t seed) : sample_count_{sample_count}, seed_{seed} {}
+        counter_sampler(int sample_count, fcgpu_sampler_config const& config) : sample_count_{sample_count}, config_{config} {}
 
         std::unique_ptr<sampler_source> clone() const override
         {
-            return std::unique_ptr<sampler_source>(new counter_sampler{sample_count_, seed_});
+            return std::unique_ptr<sampler_source>(new counter_sampler{sample_count_, config_});
         }
         int get_sample_count() const override { return sample_count_; }
         void set_sample(vector2i const& pixel, int sample) override
         {
-            key_ = fcgpu_sample_key(seed_, static_cast<std::uint32_t>(pixel.x), static_cast<std::uint32_t>(pixel.y),
-                                    static_cast<std::uint32_t>(sample));
+            stream_ = fcgpu_stream_begin(&config_, static_cast<std::uint32_t>(pixel.x), static_cast<std::uint32_t>(pixel.y),
+                                         static_cast<std::uint32_t>(sample));
             dim_ = 0;
         }
         vector2 get() override
         {
-            std::uint64_t bits{fcgpu_sample_bits(key_, dim_++)};
+            std::uint64_t bits{fcgpu_stream_bits(&config_, stream_, dim_++)};
             return {fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE, fcgpu_sample_y24(bits) * FCGPU_SAMPLER_SCALE};
         }
         void advance_dimension(int count = 1) override { dim_ += static_cast<std::uint32_t>(count); }
@@ -99,8 +102,8 @@ namespace
 
     private:
         int sample_count_{};
-        std::uint64_t seed_{};
-        std::uint64_t key_{};
+        fcgpu_sampler_config config_{};
+        fcgpu_sample_stream stream_{};
         std::uint32_t dim_{};
     };
 
@@ -471,7 +474,8 @@ extern "C"
             // renderer::worker_thread, renderer.hpp:154-179
             paged_allocator pages{1024 * 1024};
             allocator_wrapper sample_allocator{&pages};
-            counter_sampler sampler{static_cast<int>(sample_count), seed};
+            counter_sampler sampler{static_cast<int>(sample_count),
+                                    g_stratified_count ? fcgpu_sampler_stratified(seed, g_stratified_count) : fcgpu_sampler_random(seed)};
             render_worker& wk{workers[index]};
             counting_measurement meas{wk.cam.get(), &wk.nan_count};
             while(true)
@@ -648,6 +652,8 @@ extern "C"
     }
 
     std::uint64_t fcref_ray_record_size() { return sizeof(ray_record); }
+
+    void fcref_set_stratified(std::uint32_t count) { g_stratified_count = count; }
 
     // ---- the reference's own asset loader (src/core/assets.cpp, compiled where it lies): reads
     // <root>/assets/<name>.mesh and <root>/assets/images/<name>.{metadata,asset}. fc::assets resolves

@@ -114,7 +114,7 @@ assert ray_dtype.itemsize == C.sizeof(Ray) and hit_dtype.itemsize == C.sizeof(Hi
 # every symbol include/fcgpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "fcgpu_create", "fcgpu_destroy", "fcgpu_last_error", "fcgpu_set_options", "fcgpu_upload_scene",
-    "fcgpu_set_sampler", "fcgpu_render_pass", "fcgpu_trace_closest", "fcgpu_trace_any",
+    "fcgpu_set_sampler", "fcgpu_set_sampler_stratified", "fcgpu_render_pass", "fcgpu_trace_closest", "fcgpu_trace_any",
     "fcgpu_trace_closest_device", "fcgpu_trace_any_device", "fcgpu_clear_film", "fcgpu_read_film",
     "fcgpu_film_device_ptr", "fcgpu_add_sample_count", "fcgpu_get_counters", "fcgpu_reset_counters",
     "fcgpu_sync", "fcgpu_set_profiling", "fcgpu_get_stage_times", "fcgpu_stream", "fcgpu_export_image", "fcgpu_version",

@@ -39,7 +39,7 @@ struct fcgpu_ctx
     hipStream_t stream{};
     std::string err;
     fcgpu_options opt{};
-    uint64_t seed{};
+    fcgpu_sampler_config sampler{fcgpu_sampler_random(0)};
     bool has_scene{};
     FlatScene flat;  // host copy (typed arrays are small; nodes/tris are kept for introspection)
     std::vector<void*> scene_allocs;
@@ -259,7 +259,7 @@ namespace
         B.y0 = tile.y0;
         B.tw = tile.w;
         B.div_tw = make_fastdiv(static_cast<uint32_t>(tile.w));
-        B.seed = c->seed;
+        B.sampler = c->sampler;
         B.max_len = max_len;
         B.integrator = integrator;
         B.visible_env = visible_env;
@@ -514,7 +514,15 @@ extern "C"
     int fcgpu_set_sampler(fcgpu_ctx* c, uint64_t seed)
     {
         if(!c) return FCGPU_E_INVALID;
-        c->seed = seed;
+        c->sampler = fcgpu_sampler_random(seed);
+        return FCGPU_OK;
+    }
+
+    int fcgpu_set_sampler_stratified(fcgpu_ctx* c, uint64_t seed, uint32_t sample_count)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        if(sample_count == 0 || sample_count > (1u << 24)) return fail(c, FCGPU_E_INVALID, "stratified sample_count must be in [1, 2^24]");
+        c->sampler = fcgpu_sampler_stratified(seed, sample_count);
         return FCGPU_OK;
     }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "../../include/fcgpu.h"
+#include "../../include/fcgpu_sampler.h"
 #include "fc_types.h"
 
 namespace fcg
@@ -13,7 +14,7 @@ namespace fcg
         uint32_t pix0, npix;         // pixel-in-tile range of this batch
         FastDiv div_npix, div_tw;    // slot -> (sample, pixel) and pixel -> (row, column)
         uint32_t s0, nsamp;          // sample range of this batch; slots = npix * nsamp
-        uint64_t seed;
+        fcgpu_sampler_config sampler;  // include/fcgpu_sampler.h: seed + mode (random / stratified)
         int32_t h;                   // hit index being produced / shaded: 1 = camera ray's hit
         int32_t max_len;             // max_path_length
         int32_t integrator;          // FCGPU_INTEGRATOR_*

@@ -27,9 +27,9 @@ namespace fcg
     constexpr int WAVES = BLOCK / 64;
 
     // ------------------------------------------------------------------ helpers
-    template<typename R> FC_D void draw(uint64_t key, uint32_t dim, R& x, R& y)
+    template<typename R> FC_D void draw(const Batch& B, const fcgpu_sample_stream& st, uint32_t dim, R& x, R& y)
     {
-        uint64_t bits = fcgpu_sample_bits(key, dim);
+        uint64_t bits = fcgpu_stream_bits(&B.sampler, st, dim);
         x = R(fcgpu_sample_x24(bits)) * R(FCGPU_SAMPLER_SCALE);
         y = R(fcgpu_sample_y24(bits)) * R(FCGPU_SAMPLER_SCALE);
     }
@@ -44,11 +44,11 @@ namespace fcg
         sample = B.s0 + sl;
     }
 
-    FC_D uint64_t slot_key(const Batch& B, uint32_t slot)
+    FC_D fcgpu_sample_stream slot_stream(const Batch& B, uint32_t slot)
     {
         uint32_t px, py, s;
         slot_to_pixel(B, slot, px, py, s);
-        return fcgpu_sample_key(B.seed, px, py, s);
+        return fcgpu_stream_begin(&B.sampler, px, py, s);
     }
 
     // Block-aggregated multi-queue append. Every thread of the block calls it (uniform control
@@ -166,10 +166,10 @@ namespace fcg
         {
             uint32_t px, py, s;
             slot_to_pixel(B, i, px, py, s);
-            uint64_t key = fcgpu_sample_key(B.seed, px, py, s);
+            const fcgpu_sample_stream key = fcgpu_stream_begin(&B.sampler, px, py, s);
             R dx, dy, lx, ly;
-            draw(key, 0u, dx, dy);  // sample_direction
-            draw(key, 1u, lx, ly);  // sample_point (lens)
+            draw(B, key, 0u, dx, dy);  // sample_direction
+            draw(B, key, 1u, lx, ly);  // sample_point (lens)
             const CameraRec<R>& C = S.camera;
             // perspective_camera::sample_p_and_wi, perspective_camera.hpp:29-75
             vec3<R> lens{R(0), R(0), R(0)};
@@ -321,7 +321,7 @@ namespace fcg
                             {
                                 // bsdf::sample_bxdf, bsdf.hpp:46-55, on draw `dim_lobe`.x
                                 const MaterialRec m = S.materials[S.entities[entity].material];
-                                uint64_t bits = fcgpu_sample_bits(slot_key(B, path), dim_lobe);
+                                uint64_t bits = fcgpu_stream_bits(&B.sampler, slot_stream(B, path), dim_lobe);
                                 double u = fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
                                 for(int l = m.lobe_count - 1; l >= 0; --l)
                                 {
@@ -672,18 +672,18 @@ namespace fcg
                     const MaterialRec mat = S.materials[ent.material];
                     const LobeRec<R> L = S.lobes[mat.first_lobe + hit_word_lobe(hw)];
                     const R eta_a = S.media[above].ior, eta_b = S.media[below].ior;
-                    const uint64_t key = slot_key(B, path);
+                    const fcgpu_sample_stream key = slot_stream(B, path);
                     constexpr bool DELTA = KEY == L_SPEC_REFL || KEY == L_SPEC_GLASS || KEY == L_SPEC_TRANS;
 
                     if(!DELTA && mis && S.light_count > 0u)
                     {
                         // light strategy, :52-99
-                        uint64_t bits = fcgpu_sample_bits(key, dim + 1u);
+                        uint64_t bits = fcgpu_stream_bits(&B.sampler, key, dim + 1u);
                         uint32_t li = static_cast<uint32_t>((static_cast<uint64_t>(fcgpu_sample_x24(bits)) * S.light_count) >> 24);
                         if(li >= S.light_count) li = S.light_count - 1u;  // uniform_light_distribution.hpp:13-17
                         R pdf_light = R(1) / R(S.light_count);
                         R ux, uy;
-                        draw(key, dim + 2u, ux, uy);
+                        draw(B, key, dim + 2u, ux, uy);
                         const bool is_env = S.env_kind != FCGPU_ENV_NONE && li == S.light_count - 1u;
                         if(is_env)
                         {
@@ -712,7 +712,7 @@ namespace fcg
                         {
                             // standard_light::sample_p, const_diffuse_area_light.hpp:28-42
                             const LightRec<R>& Lt = S.lights[li];
-                            uint64_t pbits = fcgpu_sample_bits(key, dim + 3u);
+                            uint64_t pbits = fcgpu_stream_bits(&B.sampler, key, dim + 3u);
                             double u_prim = fcgpu_sample_x24(pbits) * FCGPU_SAMPLER_SCALE;
                             vec3<R> pL, nL;
                             light_sample_point(S, Lt, u_prim, ux, uy, pL, nL);
@@ -744,8 +744,8 @@ namespace fcg
 
                     // BSDF strategy, :101-113 / :157-169 (u2 = first draw, u1 = second: right-to-left arguments)
                     R u1x, u1y, u2x, u2y;
-                    draw(key, dim_u2, u2x, u2y);
-                    draw(key, dim_u1, u1x, u1y);
+                    draw(B, key, dim_u2, u2x, u2y);
+                    draw(B, key, dim_u1, u1x, u1y);
                     vec3<R> value;
                     if(bsdf_sample_wi<KEY>(L, sp.f, w10, eta_a, eta_b, u1x, u1y, u2x, u2y, wn, value, pdf_w12))
                     {

@@ -25,8 +25,9 @@ namespace fcgpu
     class gpu_renderer
     {
     public:
+        // `stratified`: stratified_sampler{sample_count, seed} instead of random_sampler{sample_count, seed}
         gpu_renderer(const fcgpu_scene_desc& scene, integrator_desc integrator, std::uint32_t sample_count, std::uint64_t seed = 0,
-                     int device = 0, int precision = FCGPU_PRECISION_F32)
+                     int device = 0, int precision = FCGPU_PRECISION_F32, bool stratified = false)
             : integrator_{integrator}, sample_count_{sample_count}, width_{scene.camera.width}, height_{scene.camera.height}
         {
             if(fcgpu_create(device, &ctx_) != FCGPU_OK) throw std::runtime_error(fcgpu_last_error(nullptr));
@@ -35,7 +36,7 @@ namespace fcgpu
             opt.sort_materials = 1;
             check(fcgpu_set_options(ctx_, &opt));
             check(fcgpu_upload_scene(ctx_, &scene));
-            check(fcgpu_set_sampler(ctx_, seed));
+            check(stratified ? fcgpu_set_sampler_stratified(ctx_, seed, sample_count) : fcgpu_set_sampler(ctx_, seed));
         }
         gpu_renderer(const gpu_renderer&) = delete;
         gpu_renderer& operator=(const gpu_renderer&) = delete;

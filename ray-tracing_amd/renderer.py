@@ -42,6 +42,7 @@ def load_library():
         "fcgpu_set_options": (i32, [vp, P(A.Options)]),
         "fcgpu_upload_scene": (i32, [vp, P(A.SceneDesc)]),
         "fcgpu_set_sampler": (i32, [vp, u64]),
+        "fcgpu_set_sampler_stratified": (i32, [vp, u64, u32]),
         "fcgpu_render_pass": (i32, [vp, P(A.Tile), u32, u32, i32, i32, i32]),
         "fcgpu_trace_closest": (i32, [vp, u64, vp, vp]),
         "fcgpu_trace_any": (i32, [vp, u64, vp, vp]),
@@ -123,8 +124,12 @@ class GpuContext:
         self._scene = scene
         self.width, self.height = scene.camera.width, scene.camera.height
 
-    def set_sampler(self, seed):
-        self._check(self.lib.fcgpu_set_sampler(self.h, seed))
+    def set_sampler(self, seed, stratified=None):
+        """random_sampler-like stream, or with `stratified=sample_count` the stratified_sampler{sample_count, seed} analogue."""
+        if stratified is None:
+            self._check(self.lib.fcgpu_set_sampler(self.h, seed))
+        else:
+            self._check(self.lib.fcgpu_set_sampler_stratified(self.h, seed, stratified))
 
     def render_pass(self, sample_begin, sample_count, integrator=A.INTEGRATOR_MIS, max_path_length=10, visible_env=True,
                     tile=None):
@@ -203,14 +208,15 @@ class GpuRenderer:
 
     resolution and camera live in the scene description; `integrator` is "mis" or "bsdf" with
     its max_path_length / visible_infinity_area_light (forward_mis_integrator.hpp:9-11);
-    the sampler is the counter-based stream (seed, sample_count)."""
+    the sampler is the counter-based stream (seed, sample_count): `sampler="random"` like
+    random_sampler{n, seed}, `sampler="stratified"` like stratified_sampler{n, seed}."""
 
     def __init__(self, scene, integrator="mis", max_path_length=10, visible_infinity_area_light=True, sample_count=16,
-                 seed=0, device=0, precision="f32", tiles=None, **options):
+                 seed=0, device=0, precision="f32", tiles=None, sampler="random", **options):
         self.ctx = GpuContext(device)
         self.ctx.set_options(precision=precision, **options)
         self.ctx.upload_scene(scene)
-        self.ctx.set_sampler(seed)
+        self.ctx.set_sampler(seed, stratified=sample_count if sampler == "stratified" else None)
         self.integrator = A.INTEGRATOR_MIS if integrator == "mis" else A.INTEGRATOR_BSDF
         self.max_path_length = max_path_length
         self.visible = visible_infinity_area_light

@@ -31,3 +31,8 @@ def pixel_rel_err(img, ref):
     """per-pixel max-channel error relative to the reference pixel (floored at 1e-3 of the image mean)"""
     floor = 1e-3 * max(float(np.abs(ref).mean()), 1e-30)
     return np.abs(img - ref).max(axis=2) / np.maximum(np.abs(ref).max(axis=2), floor)
+
+
+def film_stratified(z):
+    """stratified sample count of a film fixture (None = random stream)"""
+    return (int(z["stratified"]) or None) if "stratified" in z.files else None

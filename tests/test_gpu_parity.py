@@ -14,7 +14,7 @@ Bars (stated here, repeated in DESIGN.md):
 import numpy as np
 import pytest
 
-from common import A, FILM_FIXTURES, R, RAY_FIXTURES, S, load_film, load_rays, pixel_rel_err
+from common import A, FILM_FIXTURES, R, RAY_FIXTURES, S, film_stratified, load_film, load_rays, pixel_rel_err
 from oracle import pyref
 
 pytestmark = pytest.mark.gpu
@@ -75,7 +75,7 @@ def test_closest_hit_ids_f32_near_tie_fraction(name):
 def test_radiance_f64_matches_reference(name):
     z, scene = load_film(name)
     with make_ctx(scene, "f64") as ctx:
-        ctx.set_sampler(int(z["seed"]))
+        ctx.set_sampler(int(z["seed"]), stratified=film_stratified(z))
         for tag, integ in (("mis", A.INTEGRATOR_MIS), ("bsdf", A.INTEGRATOR_BSDF)):
             ctx.clear_film()
             ctx.reset_counters()
@@ -96,7 +96,7 @@ def test_radiance_f64_matches_reference(name):
 def test_radiance_f32_within_stated_tolerance(name):
     z, scene = load_film(name)
     with make_ctx(scene, "f32") as ctx:
-        ctx.set_sampler(int(z["seed"]))
+        ctx.set_sampler(int(z["seed"]), stratified=film_stratified(z))
         ctx.render_pass(0, int(z["spp"]), A.INTEGRATOR_MIS, int(z["max_path_length"]), True)
         rgb, n = ctx.read_film()
         assert ctx.counters().stack_overflows == 0

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from common import A, FILM_FIXTURES, GOLDEN, RAY_FIXTURES, load_film, load_rays
+from common import A, FILM_FIXTURES, GOLDEN, RAY_FIXTURES, film_stratified, load_film, load_rays
 from oracle import pyref
 
 
@@ -20,7 +20,8 @@ def test_film_matches_reference(oracle, name):
     z, scene = load_film(name)
     sc = oracle.scene(scene)
     for tag, integ in (("mis", A.INTEGRATOR_MIS), ("bsdf", A.INTEGRATOR_BSDF)):
-        rgb, n, st = sc.render(int(z["spp"]), integrator=integ, max_path_length=int(z["max_path_length"]), seed=int(z["seed"]), threads=4)
+        rgb, n, st = sc.render(int(z["spp"]), integrator=integ, max_path_length=int(z["max_path_length"]), seed=int(z["seed"]), threads=4,
+                               stratified=film_stratified(z))
         ref = z[tag + "_rgb_sum"]
         assert n == int(z[tag + "_count"])
         # same algorithm in the same precision: only the order of a few double roundings differs
