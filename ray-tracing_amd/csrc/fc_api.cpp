@@ -46,8 +46,13 @@ struct fcgpu_ctx
     std::vector<void*> queue_allocs;
     SceneDev<float> s32{};
     SceneDev<double> s64{};
-    Wavefront<float> q32{};
-    Wavefront<double> q64{};
+    Wavefront<float> q32{}, q32b{};    // b: second batch slot (two batches in flight, FCGPU_STREAMS=2)
+    Wavefront<double> q64{}, q64b{};
+    int slots{1};
+    hipStream_t stream_b{};
+    hipStream_t span_stream{};         // stream the next StageSpan records on
+    QueueCounters* counters_b{};
+    hipEvent_t ev_fork{}, ev_join{}, ev_acc[2]{};
     int queue_precision{-1};
     uint32_t queue_capacity{};
     uint32_t queue_limit{};
@@ -161,12 +166,12 @@ namespace
                 return;
             }
             s.stage = stage;
-            on = hipEventRecord(s.a, c->stream) == hipSuccess;
+            on = hipEventRecord(s.a, c->span_stream ? c->span_stream : c->stream) == hipSuccess;
         }
         ~StageSpan()
         {
             if(!on) return;
-            (void)hipEventRecord(s.b, c->stream);
+            (void)hipEventRecord(s.b, c->span_stream ? c->span_stream : c->stream);
             c->spans_busy.push_back(s);
         }
     };
@@ -228,6 +233,7 @@ namespace
     int ensure_queues(fcgpu_ctx* c, uint64_t paths_in_pass)
     {
         const uint32_t limit = c->opt.max_paths_in_flight ? c->opt.max_paths_in_flight : DEFAULT_PATHS_IN_FLIGHT;
+        if(c->slots > 1) paths_in_pass = (paths_in_pass + 1) / 2;  // two batches in flight share the pass
         uint32_t cap = static_cast<uint32_t>(std::min<uint64_t>(limit, std::max<uint64_t>(paths_in_pass, 256)));
         if(c->queue_precision == c->opt.precision && c->queue_limit == limit && c->queue_capacity >= cap) return FCGPU_OK;
         c->queue_limit = limit;
@@ -235,6 +241,12 @@ namespace
         free_pool(c->queue_allocs);
         c->queue_precision = -1;
         int rc = c->opt.precision == FCGPU_PRECISION_F64 ? alloc_wavefront(c, c->q64, cap) : alloc_wavefront(c, c->q32, cap);
+        if(!rc && c->slots > 1)
+        {
+            rc = c->opt.precision == FCGPU_PRECISION_F64 ? alloc_wavefront(c, c->q64b, cap) : alloc_wavefront(c, c->q32b, cap);
+            c->q64b.counters = c->counters_b;
+            c->q32b.counters = c->counters_b;
+        }
         if(rc)
         {
             free_pool(c->queue_allocs);
@@ -246,13 +258,21 @@ namespace
     }
 
     template<typename R>
-    int run_batches(fcgpu_ctx* c, SceneDev<R> S, const Wavefront<R>& Q, const fcgpu_tile& tile, uint32_t sample_begin,
-                    uint32_t sample_count, int integrator, int max_len, int visible_env)
+    int run_batches(fcgpu_ctx* c, SceneDev<R> S, const Wavefront<R>& Qa, const Wavefront<R>& Qb, const fcgpu_tile& tile,
+                    uint32_t sample_begin, uint32_t sample_count, int integrator, int max_len, int visible_env)
     {
         S.epsilon = static_cast<R>(effective_epsilon(c));
-        LaunchCfg L{c->stream, c->grid, c->lds_pad_extend, c->lds_pad_shadow};
         const uint64_t P = static_cast<uint64_t>(tile.w) * static_cast<uint64_t>(tile.h);
-        const uint64_t cap = Q.capacity;
+        const uint64_t cap = Qa.capacity;
+        // Two batch slots (FCGPU_STREAMS=2): consecutive batches run on two streams with their own queues,
+        // so the memory-bound shade kernels of one batch can share the chip with the VALU-bound traversal
+        // of the other. Film adds stay ordered: every accumulate waits for the previous batch's.
+        uint32_t batch_index = 0;
+        if(c->slots > 1)
+        {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream_b, c->ev_fork, 0));
+        }
 
         Batch B{};
         B.x0 = tile.x0;
@@ -270,6 +290,10 @@ namespace
 
         auto run_one = [&](uint32_t pix0, uint32_t npix, uint32_t s0, uint32_t nsamp)
         {
+            const int slot = c->slots > 1 ? static_cast<int>(batch_index & 1u) : 0;
+            const Wavefront<R>& Q = slot ? Qb : Qa;
+            LaunchCfg L{slot ? c->stream_b : c->stream, c->grid, c->lds_pad_extend, c->lds_pad_shadow};
+            c->span_stream = L.stream;
             B.pix0 = pix0;
             B.npix = npix;
             B.div_npix = make_fastdiv(npix);
@@ -279,7 +303,7 @@ namespace
             B.h = 1;
             {
                 StageSpan sp{c, FCGPU_STAGE_GENERATE};
-                launch_reset_counters(L, c->counters, 0);
+                launch_reset_counters(L, Q.counters, 0);
                 launch_generate(L, S, Q, B);
             }
             c->launches += 2;
@@ -288,7 +312,7 @@ namespace
                 B.h = h;
                 if(h > 1)
                 {
-                    launch_reset_counters(L, c->counters, B.parity);
+                    launch_reset_counters(L, Q.counters, B.parity);
                     c->launches += 1;
                 }
                 {
@@ -332,11 +356,14 @@ namespace
                 }
                 B.parity ^= 1;
             }
+            if(c->slots > 1 && batch_index > 0) (void)hipStreamWaitEvent(L.stream, c->ev_acc[slot ^ 1], 0);
             {
                 StageSpan sp{c, FCGPU_STAGE_ACCUMULATE};
                 launch_accumulate(L, S, Q, B);
             }
+            if(c->slots > 1) (void)hipEventRecord(c->ev_acc[slot], L.stream);
             c->launches += 1;
+            batch_index += 1;
         };
 
         if(P >= cap)
@@ -352,6 +379,12 @@ namespace
             uint32_t per = static_cast<uint32_t>(cap / P);
             for(uint32_t s = 0; s < sample_count; s += per)
                 run_one(0, static_cast<uint32_t>(P), sample_begin + s, std::min(per, sample_count - s));
+        }
+        c->span_stream = nullptr;
+        if(c->slots > 1)
+        {
+            HIP_TRY(c, hipEventRecord(c->ev_join, c->stream_b));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         }
         hipError_t e = hipGetLastError();
         if(e != hipSuccess) return hip_fail(c, e, "kernel launch");
@@ -462,6 +495,15 @@ extern "C"
         if(const char* e = std::getenv("FCGPU_FINISH_MIN")) c->finish_min = std::max(1, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_DESCEND_MIN")) c->descend_min = std::max(0, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_GRID_MULT")) c->grid = std::max(1, prop.multiProcessorCount) * std::max(1, std::atoi(e));
+        if(const char* e = std::getenv("FCGPU_STREAMS")) c->slots = std::atoi(e) >= 2 ? 2 : 1;
+        if(c->slots > 1)
+        {
+            if((e = hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+            if((e = hipMalloc(reinterpret_cast<void**>(&c->counters_b), sizeof(QueueCounters))) != hipSuccess) return bail(e, "hipMalloc");
+            if((e = hipMemset(c->counters_b, 0, sizeof(QueueCounters))) != hipSuccess) return bail(e, "hipMemset");
+            for(hipEvent_t* ev : {&c->ev_fork, &c->ev_join, &c->ev_acc[0], &c->ev_acc[1]})
+                if((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+        }
         *out = c;
         return FCGPU_OK;
     }
@@ -494,6 +536,13 @@ extern "C"
         free_pool(c->queue_allocs);
         if(c->film) (void)hipFree(c->film);
         (void)hipFree(c->counters);
+        if(c->slots > 1)
+        {
+            (void)hipStreamSynchronize(c->stream_b);
+            (void)hipFree(c->counters_b);
+            (void)hipStreamDestroy(c->stream_b);
+            for(hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_acc[0], c->ev_acc[1]}) (void)hipEventDestroy(ev);
+        }
         (void)hipFree(c->stats);
         (void)hipStreamDestroy(c->stream);
         delete c;
@@ -590,8 +639,8 @@ extern "C"
         int rc = ensure_queues(c, static_cast<uint64_t>(tile->w) * static_cast<uint64_t>(tile->h) * sample_count);
         if(rc) return rc;
         if(c->opt.precision == FCGPU_PRECISION_F64)
-            return run_batches(c, c->s64, c->q64, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
-        return run_batches(c, c->s32, c->q32, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
+            return run_batches(c, c->s64, c->q64, c->q64b, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
+        return run_batches(c, c->s32, c->q32, c->q32b, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
     }
 
     int fcgpu_trace_closest(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits)
