@@ -63,7 +63,8 @@ typedef struct fcgpu_surface {
     uint32_t index_count;     /* multiple of 3; indices are relative to vertex_offset            */
 } fcgpu_surface;
 
-/* materials: the classes under src/materials/. Round 1 carries constant textures only (const_texture_2d_*). */
+/* materials: the classes under src/materials/ with constant textures (const_texture_2d_*); image
+ * textures on material parameters and normal maps are the next row. */
 #define FCGPU_MATERIAL_DIFFUSE 0       /* diffuse_material.hpp:18-38       color_a = reflectance               */
 #define FCGPU_MATERIAL_MIRROR 1        /* mirror_material.hpp:20-56        color_a = reflectance, roughness     */
 #define FCGPU_MATERIAL_GLASS 2         /* glass_material.hpp:19-41         color_a = reflectance, color_b = transmittance, roughness */
@@ -115,7 +116,39 @@ typedef struct fcgpu_camera {
 } fcgpu_camera;
 
 #define FCGPU_ENV_NONE 0
-#define FCGPU_ENV_CONST 1     /* const_infinity_area_light.hpp (next row, not in round 1) */
+#define FCGPU_ENV_CONST 1     /* const_infinity_area_light.hpp: env_color                      */
+#define FCGPU_ENV_TEXTURE 2   /* texture_infinity_area_light.hpp:15-131: env_texture           */
+
+/* images: what assets::get_image returns (src/core/assets.cpp:162-234 and the pixel classes under src/images); pixels are
+ * the raw bytes of the .asset file, row-major, top row first; copied at upload. */
+#define FCGPU_IMAGE_R8 0      /* 1 byte:   (v/255, 0, 0)                  r8_image.hpp      */
+#define FCGPU_IMAGE_RGB8 1    /* 3 bytes:  v/255                          rgb8_image.hpp    */
+#define FCGPU_IMAGE_SRGB8 2   /* 3 bytes:  srgb_to_rgb, core/color.hpp:13-26  srgb8_image.hpp */
+#define FCGPU_IMAGE_RGB32 3   /* 3 floats: as stored                      rgb32_image.hpp   */
+
+typedef struct fcgpu_image {
+    int32_t format;
+    int32_t width;
+    int32_t height;
+    int32_t reserved;
+    const void* pixels;
+} fcgpu_image;
+
+#define FCGPU_FILTER_BOX 0        /* image_texture.hpp:88-97   */
+#define FCGPU_FILTER_BILINEAR 1   /* image_texture.hpp:99-124 (clamp addressing) */
+
+/* texture_infinity_area_light{pr_transform{{}, rotation}, image_texture_2d_rgb{image, filter,
+ * integral_sample_count}, strength, radiance_distribution_resolution} (example_scenes.hpp:339-341) */
+typedef struct fcgpu_env_texture {
+    int32_t image;                    /* index into images */
+    int32_t filter;
+    int32_t integral_sample_count;    /* image_texture_2d_rgb::integrate, image_texture.hpp:35-78 */
+    int32_t distribution_width;       /* radiance_distribution_resolution (texture_infinity_area_light.hpp:18-38) */
+    int32_t distribution_height;
+    int32_t reserved;
+    double strength;
+    double rotation[3];               /* euler x,y,z of the light's pr_transform */
+} fcgpu_env_texture;
 
 typedef struct fcgpu_scene_desc {
     const fcgpu_surface* surfaces;
@@ -136,6 +169,10 @@ typedef struct fcgpu_scene_desc {
     int32_t reserved;
     double env_color[3];
     fcgpu_camera camera;
+    const fcgpu_image* images;        /* NULL when image_count == 0 */
+    uint32_t image_count;
+    uint32_t reserved2;
+    fcgpu_env_texture env_texture;    /* read when env_kind == FCGPU_ENV_TEXTURE */
 } fcgpu_scene_desc;
 
 /* ------------------------------------------------------------------ options / records */

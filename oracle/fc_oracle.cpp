@@ -154,6 +154,224 @@ namespace fco
     }
 
     // ================================================================ scene
+    // ---------------------------------------------------------------- image texture + environment light
+    // image::rgb() of the four pixel classes: r8_image.hpp:22-40, rgb8_image.hpp, srgb8_image.hpp with
+    // srgb_to_rgb (core/color.hpp:13-26), rgb32_image.hpp; raw bytes as assets::load_image reads them
+    struct ImageD
+    {
+        int w{}, h{};
+        std::vector<double> rgb;
+        void decode(const fcgpu_image& im)
+        {
+            w = im.width;
+            h = im.height;
+            const size_t n = static_cast<size_t>(w) * static_cast<size_t>(h);
+            rgb.assign(3 * n, 0.0);
+            const unsigned char* b = static_cast<const unsigned char*>(im.pixels);
+            for(size_t i = 0; i < n; ++i)
+                for(int c = 0; c < 3; ++c)
+                {
+                    double v = 0.0;
+                    if(im.format == FCGPU_IMAGE_R8)
+                        v = c == 0 ? b[i] / 255.0 : 0.0;
+                    else if(im.format == FCGPU_IMAGE_RGB8)
+                        v = b[3 * i + c] / 255.0;
+                    else if(im.format == FCGPU_IMAGE_SRGB8)
+                    {
+                        double x = b[3 * i + c] / 255.0;
+                        v = x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4);
+                    }
+                    else
+                    {
+                        float f;
+                        std::memcpy(&f, b + 4 * (3 * i + c), 4);
+                        v = f;
+                    }
+                    rgb[3 * i + c] = v;
+                }
+        }
+        V3<double> texel(int x, int y) const
+        {
+            const double* p = &rgb[3 * (static_cast<size_t>(w) * y + x)];
+            return {p[0], p[1], p[2]};
+        }
+    };
+
+    // distribution_1d, distribution.hpp:23-121
+    struct Dist1
+    {
+        std::vector<double> f, cdf;
+        double integral{};
+        void build(std::vector<double> function)  // :31-59
+        {
+            f = std::move(function);
+            const size_t n = f.size();
+            cdf.assign(n + 1, 0.0);
+            for(size_t i = 1; i <= n; ++i) cdf[i] = cdf[i - 1] + f[i - 1];
+            integral = cdf[n] / static_cast<double>(n);
+            if(integral != 0.0)
+            {
+                for(size_t i = 1; i <= n; ++i) cdf[i] /= static_cast<double>(n) * integral;
+            }
+            else
+            {
+                integral = 1.0;
+                for(size_t i = 1; i <= n; ++i)
+                {
+                    f[i - 1] = 1.0;
+                    cdf[i] = static_cast<double>(i) / static_cast<double>(n);
+                }
+            }
+        }
+        void sample_continuous(double u, double& x, double& pdf, size_t& index) const  // :62-77
+        {
+            u = std::clamp(u, 0.0, 0x1.fffffffffffffp-1);
+            size_t upper = static_cast<size_t>(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+            size_t lower = upper - 1;
+            double du = (u - cdf[lower]) / (cdf[upper] - cdf[lower]);
+            x = (static_cast<double>(lower) + du) / static_cast<double>(f.size());
+            pdf = f[lower] / integral;
+            index = lower;
+        }
+        double pdf_continuous(double x, size_t& index) const  // :79-87
+        {
+            index = std::clamp(static_cast<size_t>(x * static_cast<double>(f.size())), size_t{0}, f.size() - 1);
+            return f[index] / integral;
+        }
+    };
+
+    template<typename R>
+    struct EnvTexture  // texture_infinity_area_light.hpp:15-131
+    {
+        bool on{};
+        ImageD image;
+        int filter{}, integral_samples{};
+        R strength{};
+        Transform<R> xf{};
+        std::vector<Dist1> rows;  // distribution_2d, distribution.hpp:124-166
+        Dist1 marginal;
+
+        // image_texture_2d_rgb::evaluate, image_texture.hpp:22-33 with box :88-97 and bilinear :99-124
+        template<typename T> V3<T> evaluate(T u, T v) const
+        {
+            const int W = image.w, H = image.h;
+            auto tx = [&](int x, int y) {
+                V3<double> t = image.texel(x, y);
+                return V3<T>{static_cast<T>(t.x), static_cast<T>(t.y), static_cast<T>(t.z)};
+            };
+            if(filter == FCGPU_FILTER_BILINEAR)
+            {
+                T ax = u * T(W) - T(0.5), ay = v * T(H) - T(0.5);
+                int x0 = static_cast<int>(std::floor(ax)), y0 = static_cast<int>(std::floor(ay));
+                int px0 = std::clamp(x0, 0, W - 1), px1 = std::clamp(x0 + 1, 0, W - 1);
+                int py0 = std::clamp(y0, 0, H - 1), py1 = std::clamp(y0 + 1, 0, H - 1);
+                V3<T> v00 = tx(px0, py0), v10 = tx(px1, py0), v01 = tx(px0, py1), v11 = tx(px1, py1);
+                T wx = ax - T(x0), wy = ay - T(y0);
+                V3<T> a = v00 * (T(1) - wx) + v10 * wx;
+                V3<T> b = v01 * (T(1) - wx) + v11 * wx;
+                return a * (T(1) - wy) + b * wy;
+            }
+            int px = std::min(static_cast<int>(u * T(W)), W - 1), py = std::min(static_cast<int>(v * T(H)), H - 1);
+            return tx(px, py);
+        }
+
+        // image_texture_2d_rgb::integrate, image_texture.hpp:35-78 (always double: host-side set-up)
+        V3<double> integrate(double au, double av, double bu, double bv) const
+        {
+            const int W = image.w, H = image.h;
+            int p0x = static_cast<int>(std::floor(au * W)), p0y = static_cast<int>(std::floor(av * H));
+            int p1x = static_cast<int>(std::ceil(bu * W)), p1y = static_cast<int>(std::ceil(bv * H));
+            V3<double> value{};
+            for(int i = p0y; i < p1y; ++i)
+                for(int j = p0x; j < p1x; ++j)
+                {
+                    double afx = std::max(au, static_cast<double>(j) / W), afy = std::max(av, static_cast<double>(i) / H);
+                    double bfx = std::min(bu, static_cast<double>(j + 1) / W), bfy = std::min(bv, static_cast<double>(i + 1) / H);
+                    double du = (bfx - afx) / static_cast<double>(integral_samples), dv = (bfy - afy) / static_cast<double>(integral_samples);
+                    V3<double> acc{};
+                    for(int ii = 0; ii < integral_samples; ++ii)
+                    {
+                        double v = afy + (ii + 0.5) * dv;
+                        for(int jj = 0; jj < integral_samples; ++jj) acc = acc + evaluate<double>(afx + (jj + 0.5) * du, v);
+                    }
+                    value = value + acc * (du * dv);
+                }
+            return value;
+        }
+
+        void build(const fcgpu_scene_desc& d)  // constructor, :15-38
+        {
+            const fcgpu_env_texture& t = d.env_texture;
+            on = true;
+            image.decode(d.images[t.image]);
+            filter = t.filter;
+            integral_samples = t.integral_sample_count;
+            strength = static_cast<R>(t.strength);
+            const double zero[3]{0.0, 0.0, 0.0};
+            xf = convert<R>(make_transform(zero, t.rotation, nullptr));
+            const int nx = t.distribution_width, ny = t.distribution_height;
+            std::vector<double> yf;
+            rows.resize(ny);
+            for(int i = 0; i < ny; ++i)
+            {
+                std::vector<double> row;
+                double sin_theta = std::sin(PI * (i + 0.5) / ny);
+                for(int j = 0; j < nx; ++j)
+                {
+                    V3<double> in = integrate(j / static_cast<double>(nx), i / static_cast<double>(ny), (j + 1) / static_cast<double>(nx),
+                                              (i + 1) / static_cast<double>(ny));
+                    row.push_back((0.212671 * in.x + 0.715160 * in.y + 0.072169 * in.z) * sin_theta);  // luminance, core/color.hpp:8-11
+                }
+                rows[i].build(std::move(row));
+                yf.push_back(rows[i].integral);  // distribution.hpp:134-140
+            }
+            marginal.build(std::move(yf));
+        }
+
+        void uv_of(V3<R> wi, R& u, R& v, R& theta) const  // :58-65
+        {
+            V3<R> w = xf.inv_dir(wi);
+            theta = std::acos(std::clamp(w.y, R(-1), R(1)));
+            R p = std::atan2(w.z, w.x);
+            R phi = p < R(0) ? p + R(2) * R(PI) : p;
+            v = theta / R(PI);
+            u = R(1) - phi / (R(2) * R(PI));
+        }
+        V3<R> get_Li(V3<R> wi) const  // :56-68
+        {
+            R u, v, theta;
+            uv_of(wi, u, v, theta);
+            return evaluate<R>(u, v) * strength;
+        }
+        R pdf_wi(V3<R> wi) const  // :124-139
+        {
+            R u, v, theta;
+            uv_of(wi, u, v, theta);
+            R sin_theta = std::sin(theta);
+            if(sin_theta == R(0)) return R(0);
+            size_t iy, ix;
+            double py = marginal.pdf_continuous(static_cast<double>(v), iy);  // distribution_2d::pdf_continuous, :154-160
+            double px = rows[iy].pdf_continuous(static_cast<double>(u), ix);
+            return R(px * py) / (R(2) * R(PI) * R(PI) * sin_theta);
+        }
+        bool sample_wi(R ux, R uy, V3<R>& wi, R& pdf, V3<R>& Li) const  // :70-96
+        {
+            double sy, sx, pdf_y, pdf_x;
+            size_t iy, ix;
+            marginal.sample_continuous(static_cast<double>(uy), sy, pdf_y, iy);  // distribution_2d::sample_continuous, :143-152
+            rows[iy].sample_continuous(static_cast<double>(ux), sx, pdf_x, ix);
+            R su = R(sx), sv = R(sy);
+            R theta = sv * R(PI), phi = (R(1) - su) * R(2) * R(PI);
+            R cos_theta = std::cos(theta), sin_theta = std::sin(theta);
+            if(sin_theta == R(0)) return false;
+            Li = evaluate<R>(su, sv) * strength;
+            if(!nonzero(Li)) return false;
+            wi = xf.dir(V3<R>{sin_theta * std::cos(phi), cos_theta, sin_theta * std::sin(phi)});
+            pdf = R(pdf_x * pdf_y) / (R(2) * R(PI) * R(PI) * sin_theta);
+            return true;
+        }
+    };
+
     template<typename R>
     class Scene
     {
@@ -207,6 +425,7 @@ namespace fco
         R pixel_size{}, plane_w{}, plane_h{}, focus{}, lens_radius{};
         bool has_env{};
         V3<R> env{};
+        EnvTexture<R> envtex{};  // texture_infinity_area_light when envtex.on
         R epsilon{R(0.000001)};  // scene.hpp:182
         Medium<R> vacuum{};      // helper::dummy_medium_, integrator.hpp:115
 
@@ -248,8 +467,9 @@ namespace fco
                 }
                 entities.push_back(ent);
             }
-            has_env = d.env_kind == FCGPU_ENV_CONST;
+            has_env = d.env_kind == FCGPU_ENV_CONST || d.env_kind == FCGPU_ENV_TEXTURE;
             env = {static_cast<R>(d.env_color[0]), static_cast<R>(d.env_color[1]), static_cast<R>(d.env_color[2])};
+            if(d.env_kind == FCGPU_ENV_TEXTURE) envtex.build(d);
             build_bvh();
             // perspective_camera constructor, perspective_camera.hpp:19-27
             cam = d.camera;
@@ -1421,6 +1641,19 @@ namespace fco
         }
 
         // one sample. Returns Li with beta0 = 1; the caller applies the film semantics.
+        // infinity_area_light interface: const_infinity_area_light.hpp / texture_infinity_area_light.hpp
+        V3<R> env_Li(V3<R> wi) const { return S.envtex.on ? S.envtex.get_Li(wi) : S.env; }
+        R env_pdf(V3<R> wi) const { return S.envtex.on ? S.envtex.pdf_wi(wi) : R(1.0 / (4.0 * PI)); }
+        bool env_sample(R ux, R uy, V3<R>& wi, R& pdf, V3<R>& Li) const
+        {
+            if(S.envtex.on) return S.envtex.sample_wi(ux, uy, wi, pdf, Li);
+            if(!nonzero(S.env)) return false;  // const_infinity_area_light::sample_wi, :33-44
+            wi = sphere_uniform(ux, uy);
+            pdf = R(1.0 / (4.0 * PI));
+            Li = S.env;
+            return true;
+        }
+
         V3<R> run_once(bool mis, int max_path_length, bool visible_env, int px, int py)
         {
             // perspective_camera::sample_p_and_wi, perspective_camera.hpp:29-75; g++ evaluates the two
@@ -1451,7 +1684,7 @@ namespace fco
             Point<R> p1;
             if(!helper_raycast(cam, wi, &above, &below, p1))
             {
-                if(S.has_env && (visible_env || !mis)) Li = Li + beta * S.env;  // :29-35 / bsdf :31-37
+                if(S.has_env && (visible_env || !mis)) Li = Li + beta * env_Li(wi);  // :29-35 / bsdf :31-37
                 return Li;
             }
             V3<R> w10 = -wi;
@@ -1475,17 +1708,17 @@ namespace fco
                     {
                         R ux, uy;
                         get(ux, uy);
-                        if(nonzero(S.env))  // const_infinity_area_light::sample_wi
+                        V3<R> wl, Le;
+                        R pdf_wi;
+                        if(env_sample(ux, uy, wl, pdf_wi, Le))  // infinity_area_light::sample_wi
                         {
-                            V3<R> wl = sphere_uniform(ux, uy);
-                            R pdf_wi = R(1.0 / (4.0 * PI));
                             V3<R> f = bsdf_evaluate(bsdf, bx, w10, wl, ea, eb);
                             if(nonzero(f) && visibility_dir(p1, wl))
                             {
                                 R pdf_bsdf = bsdf_pdf_wi(bsdf, bx, w10, wl, ea, eb);
                                 R pdf_l = pdf_light * pdf_wi;
                                 R weight = power_heuristics(pdf_l, pdf_bsdf);
-                                Li = Li + (beta * f * S.env) * (weight * std::abs(dot(p1.normal, wl)) / pdf_l);
+                                Li = Li + (beta * f * Le) * (weight * std::abs(dot(p1.normal, wl)) / pdf_l);
                             }
                         }
                         advance(1);
@@ -1536,12 +1769,12 @@ namespace fco
                         if(mis && !delta)
                         {
                             R pdf_light = R(1.0 / static_cast<double>(S.light_count()));
-                            R pdf_l = pdf_light * R(1.0 / (4.0 * PI));
-                            Li = Li + power_heuristics(pdf_w12, pdf_l) * beta * S.env;  // :117-123
+                            R pdf_l = pdf_light * env_pdf(w12);
+                            Li = Li + power_heuristics(pdf_w12, pdf_l) * beta * env_Li(w12);  // :117-123
                         }
                         else
                         {
-                            Li = Li + beta * S.env;  // :173-176, bsdf :67-70
+                            Li = Li + beta * env_Li(w12);  // :173-176, bsdf :67-70
                         }
                     }
                     break;

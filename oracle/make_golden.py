@@ -29,6 +29,10 @@ FILMS = [
     ("nested_smooth", "nested_media", dict(width=40, height=40, smooth=True), 4, 10),
     ("nested_rough", "nested_media", dict(width=40, height=40, smooth=False), 4, 10),
     ("nested_noenv", "nested_media", dict(width=32, height=32, smooth=True, env=None), 4, 10),
+    # texture_infinity_area_light over image textures of the four pixel formats, thin-lens camera
+    ("envtex_rgb32", "env_texture_scene", dict(width=48, height=32), 4, 10),
+    ("envtex_srgb8_box", "env_texture_scene", dict(width=40, height=28, fmt="srgb8", filter="box", emitter=True), 4, 10),
+    ("envtex_rgb8_pinhole", "env_texture_scene", dict(width=32, height=24, fmt="rgb8", lens=0.0), 2, 6),
 ] + [("sweep_" + c, "room", dict(width=40, height=24, tess=2, center=c), 4, 10) for c in S.CENTER_MATERIALS]
 
 # stratified mode of include/fcgpu_sampler.h (the stream is ours, the integrators consuming it are the

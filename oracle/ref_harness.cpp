@@ -53,6 +53,8 @@
 #include "light_distributions/uniform_light_distribution.hpp"
 #include "lights/const_diffuse_area_light.hpp"
 #include "lights/const_infinity_area_light.hpp"
+#include "lights/texture_infinity_area_light.hpp"
+#include "textures/image_texture.hpp"
 #include "materials/diffuse_material.hpp"
 #include "materials/glass_material.hpp"
 #include "materials/mirror_material.hpp"
@@ -359,6 +361,29 @@ namespace
     };
 }
 
+namespace
+{
+    template<typename P> std::shared_ptr<fc::image> make_raw_image(fcgpu_image const& im)
+    {
+        std::size_t const n{static_cast<std::size_t>(im.width) * static_cast<std::size_t>(im.height)};
+        std::vector<P> pixels{};
+        pixels.resize(n);
+        std::memcpy(reinterpret_cast<char*>(pixels.data()), im.pixels, n * sizeof(P));
+        return std::shared_ptr<fc::raw_image<P>>{new fc::raw_image<P>{{im.width, im.height}, std::move(pixels)}};
+    }
+
+    std::shared_ptr<fc::image> make_image(fcgpu_image const& im)
+    {
+        switch(im.format)
+        {
+        case FCGPU_IMAGE_R8: return make_raw_image<fc::r8_pixel>(im);
+        case FCGPU_IMAGE_RGB8: return make_raw_image<fc::rgb8_pixel>(im);
+        case FCGPU_IMAGE_SRGB8: return make_raw_image<fc::srgb8_pixel>(im);
+        default: return make_raw_image<fc::rgb32_pixel>(im);
+        }
+    }
+}
+
 extern "C"
 {
     struct fcref_stats
@@ -411,10 +436,24 @@ extern "C"
         }
         rs->primitive_total = offset;
 
+        // images exactly as assets::load_image builds them from the raw file bytes (assets.cpp:205-231)
+        std::vector<std::shared_ptr<image>> images{};
+        for(std::uint32_t k{0}; k < d->image_count; ++k) images.push_back(make_image(d->images[k]));
+
         std::shared_ptr<infinity_area_light> env{};
         if(d->env_kind == FCGPU_ENV_CONST)
         {
             env = std::make_shared<const_infinity_area_light>(v3(d->env_color), 1.0);
+        }
+        else if(d->env_kind == FCGPU_ENV_TEXTURE)
+        {
+            // example_scenes.hpp:339-341
+            fcgpu_env_texture const& t{d->env_texture};
+            std::shared_ptr<image_texture_2d_rgb> texture{new image_texture_2d_rgb{
+                images.at(t.image), t.filter == FCGPU_FILTER_BILINEAR ? reconstruction_filter::bilinear : reconstruction_filter::box,
+                t.integral_sample_count}};
+            env = std::shared_ptr<infinity_area_light>{new texture_infinity_area_light{
+                pr_transform{{}, v3(t.rotation)}, texture, t.strength, vector2i{t.distribution_width, t.distribution_height}}};
         }
 
         wrapping_accel_factory factory{&rs->shared, &rs->accel};

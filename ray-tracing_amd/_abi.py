@@ -7,7 +7,10 @@ c_double2 = C.c_double * 2
 SURFACE_SPHERE, SURFACE_PLANE, SURFACE_MESH = 0, 1, 2
 MATERIAL_DIFFUSE, MATERIAL_MIRROR, MATERIAL_GLASS = 0, 1, 2
 MATERIAL_PLASTIC, MATERIAL_STANDARD, MATERIAL_TRANSMISSION = 3, 4, 5
-ENV_NONE, ENV_CONST = 0, 1
+ENV_NONE, ENV_CONST, ENV_TEXTURE = 0, 1, 2
+IMAGE_R8, IMAGE_RGB8, IMAGE_SRGB8, IMAGE_RGB32 = 0, 1, 2, 3
+IMAGE_FORMAT_IDS = {"r8": 0, "rgb8": 1, "srgb8": 2, "rgb32": 3}
+FILTER_BOX, FILTER_BILINEAR = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 INTEGRATOR_BSDF, INTEGRATOR_MIS = 0, 1
 
@@ -54,6 +57,18 @@ class Camera(C.Structure):
     ]
 
 
+class Image(C.Structure):
+    _fields_ = [("format", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("reserved", C.c_int32), ("pixels", C.c_void_p)]
+
+
+class EnvTexture(C.Structure):
+    _fields_ = [
+        ("image", C.c_int32), ("filter", C.c_int32), ("integral_sample_count", C.c_int32),
+        ("distribution_width", C.c_int32), ("distribution_height", C.c_int32), ("reserved", C.c_int32),
+        ("strength", C.c_double), ("rotation", c_double3),
+    ]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [
         ("surfaces", C.POINTER(Surface)), ("materials", C.POINTER(Material)),
@@ -66,6 +81,8 @@ class SceneDesc(C.Structure):
         ("env_kind", C.c_int32), ("reserved", C.c_int32),
         ("env_color", c_double3),
         ("camera", Camera),
+        ("images", C.POINTER(Image)), ("image_count", C.c_uint32), ("reserved2", C.c_uint32),
+        ("env_texture", EnvTexture),
     ]
 
 

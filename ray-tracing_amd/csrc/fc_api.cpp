@@ -126,6 +126,34 @@ namespace
         for(int k = 0; k < 3; ++k) S.env[k] = T.env[k];
         S.light_count = c->flat.light_count;
         S.env_kind = c->flat.env_kind;
+        S.envtex = EnvTex<R>{};
+        if(c->flat.env_kind == FCGPU_ENV_TEXTURE)
+        {
+            const FlatEnvTexture& e = c->flat.env_texture;
+            const FlatImage& im = c->flat.images[e.image];
+            std::vector<Vec4<R>> texels(static_cast<size_t>(im.width) * im.height);
+            for(size_t i = 0; i < texels.size(); ++i)
+                texels[i] = Vec4<R>{static_cast<R>(im.rgb[3 * i]), static_cast<R>(im.rgb[3 * i + 1]), static_cast<R>(im.rgb[3 * i + 2]), R(0)};
+            EnvTex<R>& E = S.envtex;
+            if((rc = upload(c, c->scene_allocs, texels, &E.texels))) return rc;
+            if((rc = upload(c, c->scene_allocs, e.func_x, &E.func_x))) return rc;
+            if((rc = upload(c, c->scene_allocs, e.cdf_x, &E.cdf_x))) return rc;
+            if((rc = upload(c, c->scene_allocs, e.int_x, &E.int_x))) return rc;
+            if((rc = upload(c, c->scene_allocs, e.func_y, &E.func_y))) return rc;
+            if((rc = upload(c, c->scene_allocs, e.cdf_y, &E.cdf_y))) return rc;
+            E.width = im.width;
+            E.height = im.height;
+            E.filter = e.filter;
+            E.nx = e.nx;
+            E.ny = e.ny;
+            E.strength = static_cast<R>(e.strength);
+            E.int_y = e.int_y;
+            for(int k = 0; k < 12; ++k)
+            {
+                E.fwd[k] = static_cast<R>(e.fwd[k]);
+                E.inv[k] = static_cast<R>(e.inv[k]);
+            }
+        }
         return FCGPU_OK;
     }
 
@@ -446,7 +474,7 @@ namespace
 
 extern "C"
 {
-    int fcgpu_version(void) { return 1000; }
+    int fcgpu_version(void) { return 1001; }
 
     int fcgpu_create(int device, fcgpu_ctx** out)
     {

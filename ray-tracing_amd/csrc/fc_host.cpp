@@ -732,6 +732,183 @@ namespace fcg
             out.W = c.width;
             out.H = c.height;
         }
+        // ------------------------------------------------------------ images and image textures
+        // texel decode of the reference's pixel classes: r8_image.hpp, rgb8_image.hpp, srgb8_image.hpp
+        // (core/color.hpp:13-26), rgb32_image.hpp
+        bool decode_image(const fcgpu_image& im, FlatImage& out, std::string& err)
+        {
+            if(im.width <= 0 || im.height <= 0 || im.pixels == nullptr || im.width > 32768 || im.height > 32768)
+            {
+                err = "image: bad resolution or null pixels";
+                return false;
+            }
+            const size_t n = static_cast<size_t>(im.width) * static_cast<size_t>(im.height);
+            out.width = im.width;
+            out.height = im.height;
+            out.rgb.assign(3 * n, 0.0);
+            const uint8_t* b = static_cast<const uint8_t*>(im.pixels);
+            auto srgb = [](uint8_t v) {
+                double x = v / 255.0;
+                return x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4);
+            };
+            switch(im.format)
+            {
+            case FCGPU_IMAGE_R8:
+                for(size_t i = 0; i < n; ++i) out.rgb[3 * i] = b[i] / 255.0;
+                break;
+            case FCGPU_IMAGE_RGB8:
+                for(size_t i = 0; i < 3 * n; ++i) out.rgb[i] = b[i] / 255.0;
+                break;
+            case FCGPU_IMAGE_SRGB8:
+                for(size_t i = 0; i < 3 * n; ++i) out.rgb[i] = srgb(b[i]);
+                break;
+            case FCGPU_IMAGE_RGB32:
+                for(size_t i = 0; i < 3 * n; ++i)
+                {
+                    float v;
+                    std::memcpy(&v, b + 4 * i, 4);
+                    out.rgb[i] = static_cast<double>(v);
+                }
+                break;
+            default:
+                err = "image: unknown format";
+                return false;
+            }
+            return true;
+        }
+
+        struct TexD  // image_texture_2d_rgb in double, as the reference evaluates it on the host
+        {
+            const FlatImage* im;
+            int filter;
+            D3 texel(int x, int y) const
+            {
+                const double* p = &im->rgb[3 * (static_cast<size_t>(im->width) * y + x)];
+                return {p[0], p[1], p[2]};
+            }
+            D3 evaluate(double u, double v) const  // image_texture.hpp:22-33, 88-124
+            {
+                const int W = im->width, H = im->height;
+                if(filter == FCGPU_FILTER_BILINEAR)
+                {
+                    double ax = u * W - 0.5, ay = v * H - 0.5;
+                    int x0 = static_cast<int>(std::floor(ax)), y0 = static_cast<int>(std::floor(ay));
+                    int px0 = std::clamp(x0, 0, W - 1), px1 = std::clamp(x0 + 1, 0, W - 1);
+                    int py0 = std::clamp(y0, 0, H - 1), py1 = std::clamp(y0 + 1, 0, H - 1);
+                    D3 v00 = texel(px0, py0), v10 = texel(px1, py0), v01 = texel(px0, py1), v11 = texel(px1, py1);
+                    double wx = ax - x0, wy = ay - y0;
+                    D3 a{v00.x * (1.0 - wx) + v10.x * wx, v00.y * (1.0 - wx) + v10.y * wx, v00.z * (1.0 - wx) + v10.z * wx};
+                    D3 b{v01.x * (1.0 - wx) + v11.x * wx, v01.y * (1.0 - wx) + v11.y * wx, v01.z * (1.0 - wx) + v11.z * wx};
+                    return {a.x * (1.0 - wy) + b.x * wy, a.y * (1.0 - wy) + b.y * wy, a.z * (1.0 - wy) + b.z * wy};
+                }
+                int px = std::min(static_cast<int>(u * W), W - 1), py = std::min(static_cast<int>(v * H), H - 1);
+                return texel(px, py);
+            }
+            // image_texture_2d_rgb::integrate over [a, b], image_texture.hpp:35-78 (midpoint rule per texel)
+            D3 integrate(double au, double av, double bu, double bv, int samples) const
+            {
+                const int W = im->width, H = im->height;
+                int p0x = static_cast<int>(std::floor(au * W)), p0y = static_cast<int>(std::floor(av * H));
+                int p1x = static_cast<int>(std::ceil(bu * W)), p1y = static_cast<int>(std::ceil(bv * H));
+                D3 value{0, 0, 0};
+                for(int i = p0y; i < p1y; ++i)
+                    for(int j = p0x; j < p1x; ++j)
+                    {
+                        double afx = std::max(au, static_cast<double>(j) / W), afy = std::max(av, static_cast<double>(i) / H);
+                        double bfx = std::min(bu, static_cast<double>(j + 1) / W), bfy = std::min(bv, static_cast<double>(i + 1) / H);
+                        double delta_u = (bfx - afx) / static_cast<double>(samples), delta_v = (bfy - afy) / static_cast<double>(samples);
+                        double area = delta_u * delta_v;
+                        D3 acc{0, 0, 0};
+                        for(int ii = 0; ii < samples; ++ii)
+                        {
+                            double v = afy + (ii + 0.5) * delta_v;
+                            for(int jj = 0; jj < samples; ++jj)
+                            {
+                                double u = afx + (jj + 0.5) * delta_u;
+                                D3 e = evaluate(u, v);
+                                acc.x += e.x; acc.y += e.y; acc.z += e.z;
+                            }
+                        }
+                        value.x += acc.x * area; value.y += acc.y * area; value.z += acc.z * area;
+                    }
+                return value;
+            }
+        };
+
+        // distribution_1d's constructor, distribution.hpp:31-59: returns the function integral; `f` may be rewritten
+        double build_dist1d(std::vector<double>& f, double* cdf)
+        {
+            const size_t n = f.size();
+            cdf[0] = 0.0;
+            for(size_t i = 1; i <= n; ++i) cdf[i] = cdf[i - 1] + f[i - 1];
+            double integral = cdf[n] / static_cast<double>(n);
+            if(integral != 0.0)
+            {
+                for(size_t i = 1; i <= n; ++i) cdf[i] /= static_cast<double>(n) * integral;
+            }
+            else
+            {
+                integral = 1.0;
+                for(size_t i = 1; i <= n; ++i)
+                {
+                    f[i - 1] = 1.0;
+                    cdf[i] = static_cast<double>(i) / static_cast<double>(n);
+                }
+            }
+            return integral;
+        }
+
+        // texture_infinity_area_light's constructor, texture_infinity_area_light.hpp:15-38
+        int build_env_texture(const fcgpu_scene_desc& d, FlatScene& out, std::string& err)
+        {
+            const fcgpu_env_texture& t = d.env_texture;
+            if(t.image < 0 || static_cast<uint32_t>(t.image) >= d.image_count)
+            {
+                err = "env_texture.image out of range";
+                return FCGPU_E_INVALID;
+            }
+            if(t.distribution_width <= 0 || t.distribution_height <= 0 || t.distribution_width > 16384 || t.distribution_height > 16384 ||
+               t.integral_sample_count <= 0 || (t.filter != FCGPU_FILTER_BOX && t.filter != FCGPU_FILTER_BILINEAR))
+            {
+                err = "env_texture: bad distribution resolution, integral_sample_count or filter";
+                return FCGPU_E_INVALID;
+            }
+            FlatEnvTexture& e = out.env_texture;
+            e.image = t.image;
+            e.filter = t.filter;
+            e.nx = t.distribution_width;
+            e.ny = t.distribution_height;
+            e.strength = t.strength;
+            const double zero[3]{0.0, 0.0, 0.0};
+            Xf xf = make_xf(zero, t.rotation, nullptr);
+            for(int r = 0; r < 3; ++r)
+                for(int c = 0; c < 4; ++c)
+                {
+                    e.fwd[4 * r + c] = xf.t.m[r][c];
+                    e.inv[4 * r + c] = xf.inv.m[r][c];
+                }
+            const TexD tex{&out.images[t.image], t.filter};
+            const double delta_u = static_cast<double>(e.nx), delta_v = static_cast<double>(e.ny);
+            e.func_x.resize(static_cast<size_t>(e.nx) * e.ny);
+            e.cdf_x.resize(static_cast<size_t>(e.nx + 1) * e.ny);
+            e.int_x.resize(e.ny);
+            e.cdf_y.resize(e.ny + 1);
+            std::vector<double> row(e.nx);
+            for(int i = 0; i < e.ny; ++i)
+            {
+                double sin_theta = std::sin(3.14159265358979323846 * (i + 0.5) / e.ny);
+                for(int j = 0; j < e.nx; ++j)
+                {
+                    D3 integral = tex.integrate(j / delta_u, i / delta_v, (j + 1) / delta_u, (i + 1) / delta_v, t.integral_sample_count);
+                    row[j] = (0.212671 * integral.x + 0.715160 * integral.y + 0.072169 * integral.z) * sin_theta;  // core/color.hpp:8-11
+                }
+                e.int_x[i] = build_dist1d(row, &e.cdf_x[static_cast<size_t>(i) * (e.nx + 1)]);
+                std::copy(row.begin(), row.end(), e.func_x.begin() + static_cast<size_t>(i) * e.nx);
+            }
+            e.func_y = e.int_x;  // distribution_2d: the y function is the row integrals (distribution.hpp:134-140)
+            e.int_y = build_dist1d(e.func_y, e.cdf_y.data());
+            return FCGPU_OK;
+        }
     }  // namespace
 
     int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err)
@@ -998,6 +1175,24 @@ namespace fcg
             return FCGPU_E_LIMIT;
         }
 
+        if(d.image_count > 0 && d.images == nullptr)
+        {
+            err = "image_count > 0 with null images";
+            return FCGPU_E_INVALID;
+        }
+        out.images.resize(d.image_count);
+        for(uint32_t k = 0; k < d.image_count; ++k)
+            if(!decode_image(d.images[k], out.images[k], err)) return FCGPU_E_INVALID;
+        if(d.env_kind != FCGPU_ENV_NONE && d.env_kind != FCGPU_ENV_CONST && d.env_kind != FCGPU_ENV_TEXTURE)
+        {
+            err = "unknown env_kind";
+            return FCGPU_E_INVALID;
+        }
+        if(d.env_kind == FCGPU_ENV_TEXTURE)
+        {
+            int rc = build_env_texture(d, out, err);
+            if(rc) return rc;
+        }
         out.light_count = static_cast<uint32_t>(lights.size()) + (d.env_kind != FCGPU_ENV_NONE ? 1u : 0u);
         out.env_kind = d.env_kind;
         for(int k = 0; k < 3; ++k)

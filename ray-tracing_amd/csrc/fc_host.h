@@ -9,6 +9,21 @@
 
 namespace fcg
 {
+    struct FlatImage  // decoded as image::rgb() returns it
+    {
+        int32_t width{}, height{};
+        std::vector<double> rgb;  // 3 per texel, row-major, top row first
+    };
+
+    struct FlatEnvTexture  // texture_infinity_area_light: texture parameters + radiance distribution
+    {
+        int32_t image{-1}, filter{}, nx{}, ny{};
+        double strength{};
+        double fwd[12]{}, inv[12]{};
+        std::vector<double> func_x, cdf_x, int_x, func_y, cdf_y;
+        double int_y{};
+    };
+
     template<typename R>
     struct FlatTyped  // arrays whose element type depends on the arithmetic type
     {
@@ -33,6 +48,8 @@ namespace fcg
         FlatTyped<double> f64;
         uint32_t light_count{};   // incl. the environment light when present (scene.hpp:66-70)
         int32_t env_kind{};
+        std::vector<FlatImage> images;
+        FlatEnvTexture env_texture;
         uint32_t max_stack{};     // worst-case traversal stack depth of the wide BVH
         uint32_t binary_nodes{};
         uint32_t lobe_mask{};     // bit t set when some material can pick lobe type t

@@ -18,6 +18,7 @@
 
 #include "../../include/fcgpu_sampler.h"
 #include "fc_bsdf.h"
+#include "fc_env.h"
 #include "fc_kernels.h"
 #include "fc_traverse.h"
 
@@ -687,19 +688,19 @@ namespace fcg
                         const bool is_env = S.env_kind != FCGPU_ENV_NONE && li == S.light_count - 1u;
                         if(is_env)
                         {
-                            // const_infinity_area_light::sample_wi, const_infinity_area_light.hpp:33-44
-                            vec3<R> env = rgb(S.env);
-                            if(env.x != R(0) || env.y != R(0) || env.z != R(0))
+                            // infinity_area_light::sample_wi: const_infinity_area_light.hpp:33-44 /
+                            // texture_infinity_area_light.hpp:70-96; then forward_mis_integrator.hpp:56-72
+                            vec3<R> wi, Le;
+                            R pdf_wi;
+                            if(env_sample(S, ux, uy, wi, pdf_wi, Le))
                             {
-                                vec3<R> wi = sample_sphere_uniform(ux, uy);
-                                R pdf_wi = R(1) / (R(4) * consts<R>::pi);
                                 vec3<R> f = bsdf_evaluate<KEY>(L, sp.f, w10, wi, eta_a, eta_b);
                                 if(f.x != R(0) || f.y != R(0) || f.z != R(0))
                                 {
                                     R pdf_bsdf = bsdf_pdf_wi<KEY>(L, sp.f, w10, wi, eta_a, eta_b);
                                     R pdf_l = pdf_light * pdf_wi;
                                     R weight = power_heuristic(pdf_l, pdf_bsdf);
-                                    vec3<R> c = (beta * f * env) * (weight * r_abs(dot(ng, wi)) / pdf_l);  // :68
+                                    vec3<R> c = (beta * f * Le) * (weight * r_abs(dot(ng, wi)) / pdf_l);  // :68
                                     vec3<R> o = dot(ng, wi) > R(0) ? sp.p + ng * S.epsilon : sp.p - ng * S.epsilon;  // scene.hpp:144-157
                                     emit_shadow = true;
                                     s0 = Vec4<R>{o.x, o.y, o.z, wi.x};
@@ -807,7 +808,8 @@ namespace fcg
             unpack_ids(h1, prim, path);
             PathState<R>& st = Q.state[path];
             vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
-            vec3<R> env = rgb(S.env);
+            const vec3<R> w{st.w[0], st.w[1], st.w[2]};  // direction of the ray that left the scene
+            vec3<R> env = env_Li(S, w);
             R weight = R(1);
             if(B.h == 1)
             {
@@ -816,7 +818,7 @@ namespace fcg
             else if(mis && !(st.flags & 1u))
             {
                 R pdf_light = R(1) / R(S.light_count);
-                R pdf_light_w12 = pdf_light * (R(1) / (R(4) * consts<R>::pi));
+                R pdf_light_w12 = pdf_light * env_pdf(S, w);
                 weight = power_heuristic(st.pdf, pdf_light_w12);
             }
             if(weight != R(0) || weight != weight)

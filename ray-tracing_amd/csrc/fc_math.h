@@ -44,6 +44,12 @@ namespace fcg
     FC_HD double r_sin(double a) { return sin(a); }
     FC_HD float r_cos(float a) { return cosf(a); }
     FC_HD double r_cos(double a) { return cos(a); }
+    FC_HD float r_acos(float a) { return acosf(a); }
+    FC_HD double r_acos(double a) { return acos(a); }
+    FC_HD float r_atan2(float a, float b) { return atan2f(a, b); }
+    FC_HD double r_atan2(double a, double b) { return atan2(a, b); }
+    FC_HD float r_floor(float a) { return floorf(a); }
+    FC_HD double r_floor(double a) { return floor(a); }
     FC_HD float r_exp(float a) { return expf(a); }
     FC_HD double r_exp(double a) { return exp(a); }
     FC_HD float r_min(float a, float b) { return fminf(a, b); }

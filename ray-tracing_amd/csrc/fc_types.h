@@ -149,6 +149,28 @@ namespace fcg
         R inv_area;           // pdf_p = 1 / area (mesh_surface.hpp:292, sphere :170, plane :129)
     };
 
+    // texture_infinity_area_light (texture_infinity_area_light.hpp:15-131): the image texture
+    // (decoded texels, image_texture.hpp:88-124) and its radiance distribution (distribution.hpp:
+    // 23-166; kept in double like the light CDFs so that discrete picks equal the reference's).
+    template<typename R> struct Vec4;
+    template<typename R>
+    struct EnvTex
+    {
+        const Vec4<R>* texels;    // rgb of image::rgb(), row-major, top row first
+        int32_t width, height;
+        int32_t filter;           // FCGPU_FILTER_*
+        int32_t nx, ny;           // distribution resolution
+        int32_t pad;
+        R strength;
+        R fwd[12], inv[12];       // the light's pr_transform (rotation only) and its inverse
+        const double* func_x;     // [ny][nx]   row functions (luminance(integral) * sin theta), after distribution_1d's zero-row rule
+        const double* cdf_x;      // [ny][nx+1]
+        const double* int_x;      // [ny]       function integrals of the rows
+        const double* func_y;     // [ny]
+        const double* cdf_y;      // [ny+1]
+        double int_y;
+    };
+
     template<typename R>
     struct CameraRec
     {
@@ -177,6 +199,7 @@ namespace fcg
         int32_t env_kind;
         R env[3];
         R epsilon;
+        EnvTex<R> envtex;     // env_kind == FCGPU_ENV_TEXTURE
     };
 
     // ---- wavefront queues

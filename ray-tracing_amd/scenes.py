@@ -24,6 +24,8 @@ class Scene:
         self.camera = A.Camera()
         self.env_kind = A.ENV_NONE
         self.env_color = (0.0, 0.0, 0.0)
+        self.images = []          # (format id, contiguous pixel array of shape (height, width, channels))
+        self.env_texture = A.EnvTexture()
         self._keep = None
 
     # ---- surfaces
@@ -117,6 +119,31 @@ class Scene:
         self.env_kind = A.ENV_CONST
         self.env_color = tuple(color)
 
+    def image(self, pixels, fmt):
+        """An image as assets::get_image returns it: raw pixels (height, width[, channels]) in format
+        'r8' | 'rgb8' | 'srgb8' | 'rgb32' (see assets.py). Returns its index."""
+        from . import assets as AS
+        dtype, ch = AS.IMAGE_FORMATS[fmt]
+        px = np.ascontiguousarray(pixels, dtype=dtype)
+        if px.ndim == 2:
+            px = px[:, :, None]
+        assert px.ndim == 3 and px.shape[2] == ch
+        self.images.append((A.IMAGE_FORMAT_IDS[fmt], np.ascontiguousarray(px)))
+        return len(self.images) - 1
+
+    def set_env_texture(self, image, strength=1.0, rotation=(0, 0, 0), filter="bilinear", integral_sample_count=4,
+                        distribution_resolution=None):
+        """texture_infinity_area_light{{{}, rotation}, image_texture_2d_rgb{image, filter, integral_sample_count},
+        strength, distribution_resolution}; the resolution defaults to the image's (example_scenes.hpp:339-341)."""
+        h, w = self.images[image][1].shape[:2]
+        dw, dh = distribution_resolution if distribution_resolution is not None else (w, h)
+        self.env_kind = A.ENV_TEXTURE
+        t = A.EnvTexture(image=image, filter=A.FILTER_BILINEAR if filter == "bilinear" else A.FILTER_BOX,
+                         integral_sample_count=integral_sample_count, distribution_width=dw, distribution_height=dh,
+                         strength=strength)
+        t.rotation[:] = rotation
+        self.env_texture = t
+
     # ---- queries
     def primitive_counts(self):
         out = []
@@ -150,7 +177,13 @@ class Scene:
         d.env_kind = self.env_kind
         d.env_color[:] = self.env_color
         d.camera = self.camera
-        self._keep = (surf, mats, meds, ents, pos, nrm, uv, idx)
+        imgs = (A.Image * max(1, len(self.images)))()
+        for k, (fmt, px) in enumerate(self.images):
+            imgs[k] = A.Image(format=fmt, width=px.shape[1], height=px.shape[0], pixels=px.ctypes.data)
+        d.images = imgs
+        d.image_count = len(self.images)
+        d.env_texture = self.env_texture
+        self._keep = (surf, mats, meds, ents, pos, nrm, uv, idx, imgs)
         return d
 
 
@@ -381,4 +414,39 @@ def primitives_zoo(width=128, height=128):
     return sc
 
 
-BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo}
+def sky_image(width=32, height=16, fmt="rgb32"):
+    """A small procedural latitude-longitude environment: horizon-bright sky, dark ground, a sun blob
+    (values up to ~60 in rgb32; tone-mapped into bytes for the 8-bit formats)."""
+    v, u = np.meshgrid((np.arange(height) + 0.5) / height, (np.arange(width) + 0.5) / width, indexing="ij")
+    up = np.cos(v * math.pi)
+    sky = np.where(up > 0, 0.35 + 0.9 * (1 - up) ** 3, 0.06)[:, :, None] * np.array([0.55, 0.75, 1.0])
+    sun = 60.0 * np.exp(-(((u - 0.3) * 2) ** 2 + (v - 0.28) ** 2) / 0.004)[:, :, None] * np.array([1.0, 0.85, 0.6])
+    img = sky + sun
+    if fmt == "rgb32":
+        return img.astype(np.float32)
+    byte = np.clip(255.0 * (img / (1.0 + img)) ** (1 / 2.2), 0, 255).astype(np.uint8)
+    return byte[:, :, 0] if fmt == "r8" else byte
+
+
+def env_texture_scene(width=96, height=64, fmt="rgb32", filter="bilinear", lens=0.05, emitter=False):
+    """Open scene under a texture_infinity_area_light (the lighting of scene_mask,
+    example_scenes.hpp:339-341, incl. its thin-lens camera :350): diffuse floor, mirror and glass
+    spheres, a mesh box with a rough standard material; optionally a small emitter so that the
+    light pick has two candidates."""
+    sc = Scene()
+    sc.entity(sc.plane((0, 0, 0), (30, 30)), sc.diffuse((0.6, 0.6, 0.6)))
+    sc.entity(sc.sphere((-1.6, 1.0, 0.0), 1.0), sc.mirror((0.9, 0.9, 0.9), (0.1, 0.1)))
+    sc.entity(sc.sphere((1.2, 0.8, 0.8), 0.8), sc.glass((1, 1, 1), (1, 1, 1), (0.0, 0.0)), medium=sc.medium(1, 1.5, (0.8, 0.9, 0.5), 0.3))
+    bp, bi = box_outward((-0.6, 0.0, -0.6), (0.6, 1.2, 0.6))
+    sc.entity(sc.mesh(bp, bi, position=(0.2, 0.0, -2.2), rotation=(0, 0.5, 0)), sc.standard((0.8, 0.3, 0.2), 0.3, 0.4, 1.45))
+    if emitter:
+        sc.entity(sc.sphere((0.0, 3.5, 1.0), 0.3), sc.diffuse((0.1, 0.1, 0.1)), emission=(1.0, 0.8, 0.6), strength=8.0)
+    img = sc.image(sky_image(32, 16, fmt), fmt)
+    sc.set_env_texture(img, strength=1.5, rotation=(0.2, 1.1, 0.0), filter=filter, integral_sample_count=4 if filter == "bilinear" else 2)
+    sc.set_camera((0.5, 2.2, 7.0), (math.radians(10.0), math.radians(183.0), 0.0), math.radians(40.0), width, height,
+                  lens_radius=lens, focus_distance=7.0)
+    return sc
+
+
+BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo,
+            "env_texture_scene": env_texture_scene}
