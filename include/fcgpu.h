@@ -218,7 +218,9 @@ typedef struct fcgpu_counters {
     uint64_t bvh_nodes;         /* wide nodes uploaded                                            */
     uint64_t primitives;
     uint64_t kernel_launches;
-    uint64_t reserved[7];
+    uint64_t reserved[7];       /* diagnostics: [0] medium-stack overflows, [1] worst-case traversal stack of the BVH,
+                                   [2] binary BVH nodes, [3] node steps, [4] primitive tests, [5] traversal-stack
+                                   pushes spilled to global memory (deep BVHs only) */
 } fcgpu_counters;
 
 /* per-stage device time, measured with HIP events on the context's stream around each launch

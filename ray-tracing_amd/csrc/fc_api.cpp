@@ -49,6 +49,7 @@ struct fcgpu_ctx
     Wavefront<float> q32{}, q32b{};    // b: second batch slot (two batches in flight, FCGPU_STREAMS=2)
     Wavefront<double> q64{}, q64b{};
     int slots{1};
+    uint32_t* stack_spill{};           // scene_allocs entry: traversal stack entries beyond STACK_CAP, per grid lane
     hipStream_t stream_b{};
     hipStream_t span_stream{};         // stream the next StageSpan records on
     QueueCounters* counters_b{};
@@ -126,6 +127,8 @@ namespace
         for(int k = 0; k < 3; ++k) S.env[k] = T.env[k];
         S.light_count = c->flat.light_count;
         S.env_kind = c->flat.env_kind;
+        S.stack_spill = c->stack_spill;
+        S.stack_spill_stride = static_cast<uint32_t>(c->grid) * 256u;
         S.envtex = EnvTex<R>{};
         if(c->flat.env_kind == FCGPU_ENV_TEXTURE)
         {
@@ -619,6 +622,17 @@ extern "C"
         c->has_scene = false;
         c->flat = std::move(flat);
 
+        c->stack_spill = nullptr;
+        if(c->flat.max_stack > static_cast<uint32_t>(STACK_CAP))
+        {
+            // deep BVH: the part of the worst-case stack beyond the LDS entries lives in global memory,
+            // one column per lane of the persistent grid
+            void* p = nullptr;
+            const size_t entries = c->flat.max_stack - static_cast<uint32_t>(STACK_CAP);
+            HIP_TRY(c, hipMalloc(&p, entries * static_cast<size_t>(c->grid) * 256u * sizeof(uint32_t)));
+            c->scene_allocs.push_back(p);
+            c->stack_spill = static_cast<uint32_t*>(p);
+        }
         SceneDev<float> a{};
         if((rc = upload(c, c->scene_allocs, c->flat.nodes, &a.nodes))) return rc;
         if((rc = upload(c, c->scene_allocs, c->flat.tris, &a.tris))) return rc;
@@ -758,6 +772,7 @@ extern "C"
         out->reserved[2] = c->flat.binary_nodes;
         out->reserved[3] = st[ST_NODES];
         out->reserved[4] = st[ST_PRIMS];
+        out->reserved[5] = st[ST_STACK_SPILL];
         return FCGPU_OK;
     }
 

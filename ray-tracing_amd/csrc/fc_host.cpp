@@ -1245,9 +1245,9 @@ namespace fcg
         }
         WideBuilder wb{bin, order_box, order_ki, out};
         wb.run();
-        if(out.max_stack > static_cast<uint32_t>(STACK_CAP))
+        if(out.max_stack > static_cast<uint32_t>(STACK_CAP + STACK_SPILL_MAX))
         {
-            err = "BVH needs a deeper traversal stack than STACK_CAP";
+            err = "BVH needs a deeper traversal stack than STACK_CAP + STACK_SPILL_MAX";
             return FCGPU_E_LIMIT;
         }
 

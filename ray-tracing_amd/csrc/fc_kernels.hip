@@ -212,7 +212,7 @@ namespace fcg
     // slowest ray of its wave ends; once FINISH_MIN lanes of the wave have finished (or nothing is
     // left to traverse) they resolve their hits together and take new rays (work_take).
 
-    template<typename R, bool PROF>
+    template<typename R, bool PROF, bool SPILL>
     __global__ __launch_bounds__(BLOCK) void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};  // PROF: descent, leaf cycles, trips, leaf phases, finish cycles, finish phases
@@ -221,7 +221,8 @@ namespace fcg
         uint32_t* stack = stack_lds + threadIdx.x;
         unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
         const uint32_t n = Q.counters->ray[B.parity];
-        uint32_t n_cast = 0, n_overflow = 0, n_moverflow = 0, n_nodes = 0, n_prims = 0;
+        uint32_t n_cast = 0, n_moverflow = 0, n_nodes = 0, n_prims = 0;
+        StackStats n_overflow;
         const bool last = B.h >= B.max_len;
         // dimensions per bounce: 6 for forward_mis (fcgpu_sampler.h), 3 for forward_bsdf
         // (forward_bsdf_integrator.hpp:50,56: lobe pick, then u2, u1)
@@ -373,7 +374,7 @@ namespace fcg
                     ph[5] += 1;
                 }
             }
-            trav_round<R, false, BLOCK, PROF>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims, ph);
+            trav_round<R, false, BLOCK, SPILL, PROF>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims, ph);
             n_rounds += 1;
         }
         if(PROF)
@@ -403,7 +404,8 @@ namespace fcg
             }
         }
         wave_stat_add(Q.stats, ST_CLOSEST, n_cast);
-        wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow);
+        wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost);
+        wave_stat_add(Q.stats, ST_STACK_SPILL, n_overflow.spilled);
         wave_stat_add(Q.stats, ST_MEDIUM_OVERFLOW, n_moverflow);
         wave_stat_add(Q.stats, ST_NODES, n_nodes);
         wave_stat_add(Q.stats, ST_PRIMS, n_prims);
@@ -831,7 +833,7 @@ namespace fcg
     }
 
     // ------------------------------------------------------------------ shadow
-    template<typename R>
+    template<typename R, bool SPILL>
     __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
@@ -839,7 +841,8 @@ namespace fcg
         uint32_t* stack = stack_lds + threadIdx.x;
         unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
         const uint32_t n = Q.counters->shadow;
-        uint32_t n_cast = 0, n_occ = 0, n_overflow = 0, n_nodes = 0, n_prims = 0;
+        uint32_t n_cast = 0, n_occ = 0, n_nodes = 0, n_prims = 0;
+        StackStats n_overflow;
         WorkCursor W = work_begin();
         Trav<R> T;
         T.cur = INVALID_U32;
@@ -880,11 +883,12 @@ namespace fcg
                 }
                 if(__ballot(slot != INVALID_U32) == 0ull) break;
             }
-            trav_round<R, true, BLOCK>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims);
+            trav_round<R, true, BLOCK, SPILL>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims);
         }
         wave_stat_add(Q.stats, ST_SHADOW, n_cast);
         wave_stat_add(Q.stats, ST_OCCLUDED, n_occ);
-        wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow);
+        wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost);
+        wave_stat_add(Q.stats, ST_STACK_SPILL, n_overflow.spilled);
         wave_stat_add(Q.stats, ST_NODES, n_nodes);
         wave_stat_add(Q.stats, ST_PRIMS, n_prims);
     }
@@ -941,14 +945,14 @@ namespace fcg
     }
 
     // ------------------------------------------------------------------ parity hooks
-    template<typename R>
+    template<typename R, bool SPILL>
     __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev<R> S, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits,
                                                      uint8_t* occluded, unsigned long long* stats)
     {
         __shared__ uint32_t stack[STACK_CAP * BLOCK];
         __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
         unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
-        uint32_t n_overflow = 0;
+        StackStats n_overflow;
         // block-uniform trip count: every lane of a wave takes part in the cooperative node fetches
         for(uint64_t base = static_cast<uint64_t>(blockIdx.x) * BLOCK; base < n; base += static_cast<uint64_t>(gridDim.x) * BLOCK)
         {
@@ -963,7 +967,7 @@ namespace fcg
             if(hits != nullptr)
             {
                 fcgpu_hit h{};
-                const bool hit = traverse<R, false, BLOCK>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
+                const bool hit = traverse<R, false, BLOCK, SPILL>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
                 if(hit)
                 {
                     vec3<R> p, nrm;
@@ -983,11 +987,12 @@ namespace fcg
             }
             else
             {
-                const bool hit = traverse<R, true, BLOCK>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
+                const bool hit = traverse<R, true, BLOCK, SPILL>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
                 if(active) occluded[i] = hit ? 1 : 0;
             }
         }
-        wave_stat_add(stats, ST_STACK_OVERFLOW, n_overflow);
+        wave_stat_add(stats, ST_STACK_OVERFLOW, n_overflow.lost);
+        wave_stat_add(stats, ST_STACK_SPILL, n_overflow.spilled);
     }
 
     // ------------------------------------------------------------------ launchers
@@ -997,10 +1002,13 @@ namespace fcg
     }
     template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
-        if(Q.timeline)
-            hipLaunchKernelGGL((k_extend<R, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
+        // SPILL variants only for scenes whose BVH needs more stack than the LDS holds (S.stack_spill set at upload)
+        if(S.stack_spill)
+            hipLaunchKernelGGL((k_extend<R, false, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
+        else if(Q.timeline)
+            hipLaunchKernelGGL((k_extend<R, true, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
         else
-            hipLaunchKernelGGL((k_extend<R, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
+            hipLaunchKernelGGL((k_extend<R, false, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
     }
     template<typename R> void launch_sort(const LaunchCfg& L, const Wavefront<R>& Q, const Batch& B)
     {
@@ -1025,7 +1033,10 @@ namespace fcg
     }
     template<typename R> void launch_shadow(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
-        hipLaunchKernelGGL(k_shadow<R>, dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
+        if(S.stack_spill)
+            hipLaunchKernelGGL((k_shadow<R, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
+        else
+            hipLaunchKernelGGL((k_shadow<R, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
     }
     template<typename R> void launch_accumulate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
@@ -1038,7 +1049,10 @@ namespace fcg
     template<typename R> void launch_trace(const LaunchCfg& L, const SceneDev<R>& S, uint64_t n, const fcgpu_ray* rays,
                                            fcgpu_hit* hits, uint8_t* occluded, unsigned long long* stats)
     {
-        hipLaunchKernelGGL(k_trace<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);
+        if(S.stack_spill)
+            hipLaunchKernelGGL((k_trace<R, true>), dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);
+        else
+            hipLaunchKernelGGL((k_trace<R, false>), dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);
     }
 
 #define FCG_INSTANTIATE(R)                                                                                             \

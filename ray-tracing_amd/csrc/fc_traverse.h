@@ -155,6 +155,12 @@ namespace fcg
         cb = c1;
     }
 
+    struct StackStats
+    {
+        uint32_t lost{0};     // pushes beyond every capacity: a wrong image, must stay 0 (the host sizes the spill area)
+        uint32_t spilled{0};  // pushes that went to the global spill area
+    };
+
     template<typename R> FC_D R byte_to_real(uint32_t q, int c) { return R((q >> (8 * c)) & 0xFFu); }
 
     // Entry / exit distances of the four child boxes: plane = q * a + b per axis (a = cell size / d,
@@ -208,8 +214,9 @@ namespace fcg
     // are not taken (far ones first) and returns the nearest one (or INVALID_U32 when none is hit).
     // The near / far plane of every axis is picked by the sign of the ray direction (rc.neg*), which
     // is what min/max of the two plane distances would give.
-    template<typename R, bool ANY, int STRIDE>
-    FC_D uint32_t node_step(const RayCtx<R>& rc, R t_max, uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint32_t* stack, int& sp, uint32_t& overflow)
+    template<typename R, bool ANY, int STRIDE, bool SPILL>
+    FC_D uint32_t node_step(const RayCtx<R>& rc, R t_max, uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint32_t* stack, uint32_t* spill,
+                            uint32_t spill_stride, int& sp, StackStats& overflow)
     {
         R ox = R(__builtin_bit_cast(float, n0.x)), oy = R(__builtin_bit_cast(float, n0.y)), oz = R(__builtin_bit_cast(float, n0.z));
         R ax = exp2_from_biased<R>(n0.w & 0xFFu) * rc.inv_d.x;
@@ -237,17 +244,48 @@ namespace fcg
         cswap(key[1], key[3], ch[1], ch[3]);
         cswap(key[1], key[2], ch[1], ch[2]);
         uint32_t next = key[0] != INVALID_U32 ? ch[0] : INVALID_U32;
-        // the host refuses a BVH whose worst case exceeds STACK_CAP (FCGPU_E_LIMIT): `room` is always true
-        const bool room = sp <= STACK_CAP - 3;
-        overflow += (!room && key[1] != INVALID_U32) ? 1u : 0u;
-#pragma unroll
-        for(int k = 3; k >= 1; --k)
+        if(!SPILL)
         {
-            const bool push = room && key[k] != INVALID_U32;
-            if(push) stack[sp * STRIDE] = ch[k];
-            sp += push ? 1 : 0;
+            // the BVH's worst case fits the LDS stack (checked at upload): `room` is always true
+            const bool room = sp <= STACK_CAP - 3;
+            overflow.lost += (!room && key[1] != INVALID_U32) ? 1u : 0u;
+#pragma unroll
+            for(int k = 3; k >= 1; --k)
+            {
+                const bool push = room && key[k] != INVALID_U32;
+                if(push) stack[sp * STRIDE] = ch[k];
+                sp += push ? 1 : 0;
+            }
+        }
+        else
+        {
+            // deep tree: entries beyond STACK_CAP go to this lane's column of the spill buffer
+#pragma unroll
+            for(int k = 3; k >= 1; --k)
+            {
+                if(key[k] != INVALID_U32)
+                {
+                    if(sp < STACK_CAP)
+                        stack[sp * STRIDE] = ch[k];
+                    else if(sp < STACK_CAP + STACK_SPILL_MAX)
+                    {
+                        spill[static_cast<size_t>(sp - STACK_CAP) * spill_stride] = ch[k];
+                        overflow.spilled += 1;
+                    }
+                    else
+                        overflow.lost += 1;
+                    sp += sp < STACK_CAP + STACK_SPILL_MAX ? 1 : 0;
+                }
+            }
         }
         return next;
+    }
+
+    template<int STRIDE, bool SPILL> FC_D uint32_t stack_pop(const uint32_t* stack, const uint32_t* spill, uint32_t spill_stride, int& sp)
+    {
+        sp -= 1;
+        if(SPILL && sp >= STACK_CAP) return spill[static_cast<size_t>(sp - STACK_CAP) * spill_stride];
+        return stack[sp * STRIDE];
     }
 
     // Quad-cooperative node fetch (FCG_COOP_FETCH=1; off by default). A lane that loads its own
@@ -332,12 +370,13 @@ namespace fcg
 
     // PROF (development aid): ph[0] += clock cycles in the descent loop, ph[1] += cycles in the leaf
     // phase, ph[2] += wave-level descent trips, ph[3] += leaf phases entered.
-    template<typename R, bool ANY, int STRIDE, bool PROF = false>
-    FC_D void trav_round(const SceneDev<R>& S, Trav<R>& T, uint32_t* stack, unsigned char* nodebuf, uint32_t& overflow, int descend_min,
+    template<typename R, bool ANY, int STRIDE, bool SPILL, bool PROF = false>
+    FC_D void trav_round(const SceneDev<R>& S, Trav<R>& T, uint32_t* stack, unsigned char* nodebuf, StackStats& overflow, int descend_min,
                          uint32_t& n_nodes, uint32_t& n_prims, unsigned long long* ph = nullptr)
     {
         unsigned long long c0 = 0;
         if(PROF) c0 = clock64();
+        uint32_t* spill = SPILL ? S.stack_spill + (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) : nullptr;
         uint32_t cur = T.cur;
         int sp = T.sp;
         bool leaf_waiting = __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
@@ -357,9 +396,9 @@ namespace fcg
 #else
                 const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
 #endif
-                uint32_t next = node_step<R, ANY, STRIDE>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, sp, overflow);
+                uint32_t next = node_step<R, ANY, STRIDE, SPILL>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, sp, overflow);
                 n_nodes += 1;
-                if(next == INVALID_U32 && sp > 0) next = stack[(--sp) * STRIDE];
+                if(next == INVALID_U32 && sp > 0) next = stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp);
                 cur = next;
             }
             leaf_waiting = leaf_waiting || __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
@@ -413,7 +452,7 @@ namespace fcg
                     if(ANY) stop = true;
                 }
             }
-            cur = (!stop && sp > 0) ? stack[(--sp) * STRIDE] : INVALID_U32;
+            cur = (!stop && sp > 0) ? stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
         }
         T.cur = cur;
         T.sp = sp;
@@ -422,9 +461,9 @@ namespace fcg
 
     // Whole-wave convenience wrapper (parity hooks): runs rounds until every ray of the wave is finished.
     // Lanes without a ray pass active = false (they still take part in the cooperative fetches).
-    template<typename R, bool ANY, int STRIDE>
+    template<typename R, bool ANY, int STRIDE, bool SPILL>
     FC_D bool traverse(const SceneDev<R>& S, bool active, const RayCtx<R>& rc, R t_max, uint32_t* stack, unsigned char* nodebuf, R& t_out,
-                       uint32_t& pk_out, R& b0_out, R& b1_out, uint32_t& overflow)
+                       uint32_t& pk_out, R& b0_out, R& b1_out, StackStats& overflow)
     {
         Trav<R> T;
         T.rc = rc;
@@ -435,7 +474,7 @@ namespace fcg
         T.cur = active ? 0u : INVALID_U32;
         T.sp = 0;
         uint32_t nn = 0, np = 0;
-        while(__ballot(!trav_done(T)) != 0ull) trav_round<R, ANY, STRIDE>(S, T, stack, nodebuf, overflow, 12, nn, np);
+        while(__ballot(!trav_done(T)) != 0ull) trav_round<R, ANY, STRIDE, SPILL>(S, T, stack, nodebuf, overflow, 12, nn, np);
         t_out = T.t_max;
         pk_out = T.pk;
         b0_out = T.b0;

@@ -23,7 +23,10 @@ namespace fcg
 #ifndef FCG_STACK_CAP
 #define FCG_STACK_CAP 30
 #endif
-    constexpr int STACK_CAP = FCG_STACK_CAP;  // LDS traversal stack entries per lane: 30 KB per 256-thread block, 5 blocks per CU
+    constexpr int STACK_CAP = FCG_STACK_CAP;
+    // entries beyond STACK_CAP spill to a per-lane column in global memory (allocated only for scenes
+    // whose worst case needs them): deep trees work, shallow ones pay nothing
+    constexpr int STACK_SPILL_MAX = 226;  // LDS traversal stack entries per lane: 30 KB per 256-thread block, 5 blocks per CU
 
     struct alignas(16) Node4
     {
@@ -194,6 +197,9 @@ namespace fcg
         const MediumRec<R>* media;
         const LightRec<R>* lights;
         const double* light_cdf;
+        uint32_t* stack_spill;     // [depth - STACK_CAP][grid lanes] or nullptr when the BVH fits the LDS stack
+        uint32_t stack_spill_stride;
+        uint32_t stack_spill_pad;
         CameraRec<R> camera;
         uint32_t light_count;
         int32_t env_kind;
@@ -315,7 +321,7 @@ namespace fcg
 
     enum StatIndex
     {
-        ST_CLOSEST = 0, ST_SHADOW = 1, ST_OCCLUDED = 2, ST_NAN = 3, ST_STACK_OVERFLOW = 4, ST_MEDIUM_OVERFLOW = 5, ST_NODES = 6, ST_PRIMS = 7, ST_COUNT = 8
+        ST_CLOSEST = 0, ST_SHADOW = 1, ST_OCCLUDED = 2, ST_NAN = 3, ST_STACK_OVERFLOW = 4, ST_MEDIUM_OVERFLOW = 5, ST_NODES = 6, ST_PRIMS = 7, ST_STACK_SPILL = 8, ST_COUNT = 9
     };
 
     template<typename R>

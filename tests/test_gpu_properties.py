@@ -192,3 +192,76 @@ def test_cpp_host_renders_the_room_from_asset_files(tmp_path):
     # few paths may flip a discrete decision: compare like the fp32 parity tests do
     err = pixel_rel_err(img.astype(np.float64), ref)
     assert np.mean(err < 1e-3) > 0.97 and abs(img.mean() - ref.mean()) < 0.01 * ref.mean()
+
+
+def test_deep_bvh_spills_the_traversal_stack_and_still_matches_the_oracle():
+    """A mesh whose SAH tree is very unbalanced (triangle sizes in geometric progression) needs more
+    traversal-stack entries than the LDS holds: the rest spills to global memory (fc_traverse.h)."""
+    from oracle import pyref
+
+    n, g = 420, 1.1
+    x0 = g ** np.arange(n + 1) - 1.0             # strip of quads with exponentially growing width (up to ~2e17)
+    pos = np.zeros((2 * (n + 1), 3), np.float32)
+    pos[0::2, 0], pos[1::2, 0] = x0, x0
+    pos[1::2, 2] = 1.0
+    pos[:, 1] = 0.25 * pos[:, 0] * np.where(np.arange(2 * (n + 1)) % 2 == 0, 1.0, -1.0)  # a twisted ribbon whose height grows with x: every box of the chain straddles y = 0
+    k = np.arange(n, dtype=np.uint32) * 2
+    idx = np.stack([k, k + 1, k + 2, k + 2, k + 1, k + 3], 1).reshape(-1)
+    sc = S.Scene()
+    sc.entity(sc.mesh(pos, idx), sc.diffuse((0.7, 0.7, 0.7)))
+    sc.set_env((1.0, 0.9, 0.8))  # no analytic primitive here: their quadratics are noise at coordinates of 1e30
+    sc.set_camera((20.0, 6.0, 6.0), (np.radians(40.0), np.radians(180.0), 0.0), np.radians(60.0), 48, 32)
+    rng = np.random.default_rng(5)
+    rays = np.zeros(20000, dtype=A.ray_dtype)
+    ox = g ** rng.uniform(0, n, len(rays))       # log-uniform along the strip, so every scale of the tree is visited
+    rays["origin"] = np.stack([ox, 0.3 * ox + rng.uniform(0.5, 1.0, len(rays)), rng.uniform(-0.5, 1.5, len(rays))], 1)
+    d = rng.standard_normal((len(rays), 3))
+    d[:, 0] *= 0.2
+    d[:, 1] = -np.abs(d[:, 1]) - 0.2
+    # a quarter of the rays run ALONG the ribbon from its big end towards the small one, inside every
+    # box of the chain: the SAH build peels the small triangles off first, so the near child is the
+    # interior remainder and the far (leaf) children pile up on the stack level after level
+    m = len(rays) // 4
+    slope = rng.uniform(-0.2, 0.2, m)
+    X = g ** rng.uniform(300, 400, m)
+    # (+3: the line misses the smallest triangles by a clear margin instead of grazing them, where
+    # double precision from 1e15 away decides hit or miss by rounding)
+    rays["origin"][:m] = np.stack([X, slope * X + 3.0, rng.uniform(0.1, 0.9, m)], 1)
+    d[:m] = np.stack([-np.ones(m), -slope, np.zeros(m)], 1)  # dz = 0: the ribbon is only 1 wide in z
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["t_max"] = np.inf
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision="f64")
+        ctx.upload_scene(sc)
+        c = ctx.counters()
+        assert c.reserved[1] > 30, f"scene is not deep enough to exercise the spill path (max_stack {c.reserved[1]})"
+        hits = ctx.trace_closest(rays)
+        occ = ctx.trace_any(rays)
+        ctx.render_pass(0, 4)
+        rgb, cnt = ctx.read_film()
+        c = ctx.counters()
+        assert c.stack_overflows == 0
+        assert c.reserved[5] > 0, "no push reached the spill area: the test does not cover it"
+    o = pyref.restatement("f64").scene(sc)
+    ref = o.trace_closest(rays)
+    # Rays that start 1e13..1e16 away see the small end of the ribbon collapse onto a few points in
+    # double precision: several triangles then report the SAME distance and the winner depends on the
+    # visiting order (binary tree in the reference, 4-wide here). Distances must agree everywhere; ids
+    # wherever the hit is not such a tie.
+    hit = ref["prim"] != 0xFFFFFFFF
+    hm = np.flatnonzero((hits["prim"] != 0xFFFFFFFF) != hit)
+    print("hit/miss disagreements:", len(hm), "in the along-ribbon quarter:", int((hm < len(rays) // 4).sum()),
+          [(int(i), int(hits["prim"][i]), int(ref["prim"][i]), float(hits["t"][i]), float(ref["t"][i])) for i in hm[:8]])
+    assert np.array_equal(hits["prim"] != 0xFFFFFFFF, hit)
+    assert np.allclose(hits["t"][hit], ref["t"][hit], rtol=1e-9, atol=0)
+    bad = hits["prim"] != ref["prim"]
+    print("tie mismatches among the along-ribbon rays:", int(bad.sum()))
+    assert bad.mean() < 0.01 and not bad[len(rays) // 4:].any()  # none among the ordinary rays
+    assert np.array_equal(occ.astype(bool), ref["prim"] != 0xFFFFFFFF)
+    film = o.render(4)
+    assert pixel_rel_err_max(rgb, film[0]) <= 1e-9
+
+
+def pixel_rel_err_max(a, b):
+    from common import pixel_rel_err
+    return float(pixel_rel_err(a, b).max())
