@@ -80,6 +80,19 @@ typedef struct fcgpu_material {
     double roughness[2];
     double ior;
     double metalness;
+    /* image textures (image_texture_2d_rgb / image_texture_2d_r, image_texture.hpp) in place of the
+     * constants above: 0 = constant, k > 0 = textures[k - 1], evaluated at the hit's uv.
+     * rgb parameters: color_a, color_b (every material). Single-channel parameters (.r of the image):
+     * ior (PLASTIC, STANDARD), metalness and roughness (STANDARD: its roughness is one texture_2d_r).
+     * The two-channel roughness of the other materials is a texture_2d_rg, for which the reference
+     * has no image class: constants only. tex_normal (normal maps) is not implemented yet:
+     * FCGPU_E_INVALID when set. */
+    int32_t tex_color_a;
+    int32_t tex_color_b;
+    int32_t tex_roughness;
+    int32_t tex_metalness;
+    int32_t tex_ior;
+    int32_t tex_normal;
 } fcgpu_material;
 
 /* media: src/core/medium.hpp:40-54 (uniform_medium). The implicit vacuum (priority -1, ior 1)
@@ -137,6 +150,12 @@ typedef struct fcgpu_image {
 #define FCGPU_FILTER_BOX 0        /* image_texture.hpp:88-97   */
 #define FCGPU_FILTER_BILINEAR 1   /* image_texture.hpp:99-124 (clamp addressing) */
 
+/* image_texture_2d_rgb{image, filter, .} / image_texture_2d_r{image, filter, .} as material parameters */
+typedef struct fcgpu_texture {
+    int32_t image;   /* index into images */
+    int32_t filter;
+} fcgpu_texture;
+
 /* texture_infinity_area_light{pr_transform{{}, rotation}, image_texture_2d_rgb{image, filter,
  * integral_sample_count}, strength, radiance_distribution_resolution} (example_scenes.hpp:339-341) */
 typedef struct fcgpu_env_texture {
@@ -173,6 +192,9 @@ typedef struct fcgpu_scene_desc {
     uint32_t image_count;
     uint32_t reserved2;
     fcgpu_env_texture env_texture;    /* read when env_kind == FCGPU_ENV_TEXTURE */
+    const fcgpu_texture* textures;    /* NULL when texture_count == 0 */
+    uint32_t texture_count;
+    uint32_t reserved3;
 } fcgpu_scene_desc;
 
 /* ------------------------------------------------------------------ options / records */

@@ -197,6 +197,31 @@ namespace fco
         }
     };
 
+    // image_texture_2d_rgb::evaluate, image_texture.hpp:22-33 with box :88-97 and bilinear :99-124
+    // (image_texture_2d_r, :131-141 / :193-233, is the same arithmetic on image::r() = rgb().x)
+    template<typename T> V3<T> image_evaluate(const ImageD& image, int filter, T u, T v)
+    {
+        const int W = image.w, H = image.h;
+        auto tx = [&](int x, int y) {
+            V3<double> t = image.texel(x, y);
+            return V3<T>{static_cast<T>(t.x), static_cast<T>(t.y), static_cast<T>(t.z)};
+        };
+        if(filter == FCGPU_FILTER_BILINEAR)
+        {
+            T ax = u * T(W) - T(0.5), ay = v * T(H) - T(0.5);
+            int x0 = static_cast<int>(std::floor(ax)), y0 = static_cast<int>(std::floor(ay));
+            int px0 = std::clamp(x0, 0, W - 1), px1 = std::clamp(x0 + 1, 0, W - 1);
+            int py0 = std::clamp(y0, 0, H - 1), py1 = std::clamp(y0 + 1, 0, H - 1);
+            V3<T> v00 = tx(px0, py0), v10 = tx(px1, py0), v01 = tx(px0, py1), v11 = tx(px1, py1);
+            T wx = ax - T(x0), wy = ay - T(y0);
+            V3<T> a = v00 * (T(1) - wx) + v10 * wx;
+            V3<T> b = v01 * (T(1) - wx) + v11 * wx;
+            return a * (T(1) - wy) + b * wy;
+        }
+        int px = std::min(static_cast<int>(u * T(W)), W - 1), py = std::min(static_cast<int>(v * T(H)), H - 1);
+        return tx(px, py);
+    }
+
     // distribution_1d, distribution.hpp:23-121
     struct Dist1
     {
@@ -251,29 +276,7 @@ namespace fco
         std::vector<Dist1> rows;  // distribution_2d, distribution.hpp:124-166
         Dist1 marginal;
 
-        // image_texture_2d_rgb::evaluate, image_texture.hpp:22-33 with box :88-97 and bilinear :99-124
-        template<typename T> V3<T> evaluate(T u, T v) const
-        {
-            const int W = image.w, H = image.h;
-            auto tx = [&](int x, int y) {
-                V3<double> t = image.texel(x, y);
-                return V3<T>{static_cast<T>(t.x), static_cast<T>(t.y), static_cast<T>(t.z)};
-            };
-            if(filter == FCGPU_FILTER_BILINEAR)
-            {
-                T ax = u * T(W) - T(0.5), ay = v * T(H) - T(0.5);
-                int x0 = static_cast<int>(std::floor(ax)), y0 = static_cast<int>(std::floor(ay));
-                int px0 = std::clamp(x0, 0, W - 1), px1 = std::clamp(x0 + 1, 0, W - 1);
-                int py0 = std::clamp(y0, 0, H - 1), py1 = std::clamp(y0 + 1, 0, H - 1);
-                V3<T> v00 = tx(px0, py0), v10 = tx(px1, py0), v01 = tx(px0, py1), v11 = tx(px1, py1);
-                T wx = ax - T(x0), wy = ay - T(y0);
-                V3<T> a = v00 * (T(1) - wx) + v10 * wx;
-                V3<T> b = v01 * (T(1) - wx) + v11 * wx;
-                return a * (T(1) - wy) + b * wy;
-            }
-            int px = std::min(static_cast<int>(u * T(W)), W - 1), py = std::min(static_cast<int>(v * T(H)), H - 1);
-            return tx(px, py);
-        }
+        template<typename T> V3<T> evaluate(T u, T v) const { return image_evaluate<T>(image, filter, u, v); }
 
         // image_texture_2d_rgb::integrate, image_texture.hpp:35-78 (always double: host-side set-up)
         V3<double> integrate(double au, double av, double bu, double bv) const
@@ -414,6 +417,8 @@ namespace fco
 
         std::vector<Surface> surfaces;
         std::vector<fcgpu_material> materials;
+        std::vector<ImageD> images;            // decoded, for the image textures of materials
+        std::vector<fcgpu_texture> textures;
         std::vector<Medium<R>> media;
         std::vector<Entity> entities;
         std::vector<Light> lights;
@@ -436,6 +441,12 @@ namespace fco
             vacuum.vacuum = true;
             for(uint32_t i = 0; i < d.surface_count; ++i) surfaces.push_back(make_surface(d, d.surfaces[i]));
             materials.assign(d.materials, d.materials + d.material_count);
+            if(d.texture_count)
+            {
+                textures.assign(d.textures, d.textures + d.texture_count);
+                images.resize(d.image_count);
+                for(uint32_t i = 0; i < d.image_count; ++i) images[i].decode(d.images[i]);
+            }
             for(uint32_t i = 0; i < d.medium_count; ++i)
             {
                 Medium<R> m;
@@ -1304,8 +1315,27 @@ namespace fco
     }
 
     // material::evaluate for each class (const textures; normal_mapping on its skip_ path)
-    template<typename R> Bsdf<R> material_bsdf(const fcgpu_material& m, const Point<R>& p)
+    // Image textures (image_texture_2d_rgb / _r) are evaluated at p.get_uv() like each evaluate() does.
+    template<typename R> Bsdf<R> material_bsdf(const fcgpu_material& m_in, const Point<R>& p, const Scene<R>* scene = nullptr)
     {
+        fcgpu_material m = m_in;
+        if(scene && !scene->textures.empty())
+        {
+            auto tex = [&](int32_t handle) {
+                const fcgpu_texture& t = scene->textures[static_cast<size_t>(handle - 1)];
+                return image_evaluate<R>(scene->images[static_cast<size_t>(t.image)], t.filter, p.u, p.v);
+            };
+            auto set3 = [](double* dst, V3<R> c) {
+                dst[0] = static_cast<double>(c.x);
+                dst[1] = static_cast<double>(c.y);
+                dst[2] = static_cast<double>(c.z);
+            };
+            if(m.tex_color_a > 0) set3(m.color_a, tex(m.tex_color_a));
+            if(m.tex_color_b > 0) set3(m.color_b, tex(m.tex_color_b));
+            if(m.tex_roughness > 0) m.roughness[0] = m.roughness[1] = static_cast<double>(tex(m.tex_roughness).x);
+            if(m.tex_metalness > 0) m.metalness = static_cast<double>(tex(m.tex_metalness).x);
+            if(m.tex_ior > 0) m.ior = static_cast<double>(tex(m.tex_ior).x);
+        }
         Bsdf<R> b;
         b.t = p.tangent;
         b.ns = p.shading_normal;
@@ -1693,7 +1723,7 @@ namespace fco
 
             for(int i = 2; i <= max_path_length; ++i)
             {
-                Bsdf<R> bsdf = material_bsdf(S.materials[S.entities[p1.entity].material], p1);
+                Bsdf<R> bsdf = material_bsdf(S.materials[S.entities[p1.entity].material], p1, &S);
                 int bx = sample_bxdf(bsdf, R(get_x_double()));  // :48
                 bool delta = bsdf.lobes[bx].is_delta();
                 R ea = above->ior, eb = below->ior;

@@ -33,6 +33,9 @@ FILMS = [
     ("envtex_rgb32", "env_texture_scene", dict(width=48, height=32), 4, 10),
     ("envtex_srgb8_box", "env_texture_scene", dict(width=40, height=28, fmt="srgb8", filter="box", emitter=True), 4, 10),
     ("envtex_rgb8_pinhole", "env_texture_scene", dict(width=32, height=24, fmt="rgb8", lens=0.0), 2, 6),
+    # image textures on material parameters (image_texture_2d_rgb / image_texture_2d_r), every material class
+    ("textured", "textured_scene", dict(width=48, height=32), 4, 10),
+    ("textured_len4", "textured_scene", dict(width=36, height=24), 6, 4),
 ] + [("sweep_" + c, "room", dict(width=40, height=24, tess=2, center=c), 4, 10) for c in S.CENTER_MATERIALS]
 
 # stratified mode of include/fcgpu_sampler.h (the stream is ours, the integrators consuming it are the

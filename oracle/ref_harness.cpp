@@ -283,25 +283,43 @@ namespace
         std::uint32_t primitive_total{};
     };
 
-    std::shared_ptr<material> make_material(fcgpu_material const& m)
+    // const_texture_2d_* for constants, image_texture_2d_rgb / image_texture_2d_r (textures/image_texture.hpp)
+    // where the description names an image texture (handle k > 0 = textures[k - 1])
+    std::shared_ptr<material> make_material(fcgpu_scene_desc const& d, std::vector<std::shared_ptr<image>> const& images, fcgpu_material const& m)
     {
-        auto rgb = [](double const* c) { return std::make_shared<const_texture_2d_rgb>(vector3{c[0], c[1], c[2]}); };
+        auto filter_of = [](fcgpu_texture const& t) { return t.filter == FCGPU_FILTER_BILINEAR ? reconstruction_filter::bilinear : reconstruction_filter::box; };
+        auto rgb = [&](double const* c, std::int32_t handle) -> std::shared_ptr<texture_2d_rgb> {
+            if(handle > 0)
+            {
+                fcgpu_texture const& t{d.textures[handle - 1]};
+                return std::shared_ptr<texture_2d_rgb>{new image_texture_2d_rgb{images.at(t.image), filter_of(t), 1}};
+            }
+            return std::make_shared<const_texture_2d_rgb>(vector3{c[0], c[1], c[2]});
+        };
         auto rg = [](double const* c) { return std::make_shared<const_texture_2d_rg>(vector2{c[0], c[1]}); };
-        auto r = [](double c) { return std::make_shared<const_texture_2d_r>(c); };
+        auto r = [&](double c, std::int32_t handle) -> std::shared_ptr<texture_2d_r> {
+            if(handle > 0)
+            {
+                fcgpu_texture const& t{d.textures[handle - 1]};
+                return std::shared_ptr<texture_2d_r>{new image_texture_2d_r{images.at(t.image), filter_of(t), 1}};
+            }
+            return std::make_shared<const_texture_2d_r>(c);
+        };
         switch(m.kind)
         {
         case FCGPU_MATERIAL_DIFFUSE:
-            return std::make_shared<diffuse_material>(rgb(m.color_a), nullptr);
+            return std::make_shared<diffuse_material>(rgb(m.color_a, m.tex_color_a), nullptr);
         case FCGPU_MATERIAL_MIRROR:
-            return std::make_shared<mirror_material>(rgb(m.color_a), rg(m.roughness));
+            return std::make_shared<mirror_material>(rgb(m.color_a, m.tex_color_a), rg(m.roughness));
         case FCGPU_MATERIAL_GLASS:
-            return std::make_shared<glass_material>(rgb(m.color_a), rgb(m.color_b), rg(m.roughness));
+            return std::make_shared<glass_material>(rgb(m.color_a, m.tex_color_a), rgb(m.color_b, m.tex_color_b), rg(m.roughness));
         case FCGPU_MATERIAL_PLASTIC:
-            return std::make_shared<plastic_material>(rgb(m.color_a), rgb(m.color_b), rg(m.roughness), r(m.ior));
+            return std::make_shared<plastic_material>(rgb(m.color_a, m.tex_color_a), rgb(m.color_b, m.tex_color_b), rg(m.roughness), r(m.ior, m.tex_ior));
         case FCGPU_MATERIAL_STANDARD:
-            return std::make_shared<standard_material>(rgb(m.color_a), r(m.metalness), r(m.roughness[0]), r(m.ior), nullptr);
+            return std::make_shared<standard_material>(rgb(m.color_a, m.tex_color_a), r(m.metalness, m.tex_metalness), r(m.roughness[0], m.tex_roughness),
+                                                       r(m.ior, m.tex_ior), nullptr);
         case FCGPU_MATERIAL_TRANSMISSION:
-            return std::make_shared<transmission_material>(rgb(m.color_b), rg(m.roughness));
+            return std::make_shared<transmission_material>(rgb(m.color_b, m.tex_color_b), rg(m.roughness));
         default:
             return nullptr;
         }
@@ -406,9 +424,13 @@ extern "C"
             rs->surfaces.push_back(make_surface(*d, d->surfaces[i]));
             if(rs->surfaces.back() == nullptr) { delete rs; return nullptr; }
         }
+        // images exactly as assets::load_image builds them from the raw file bytes (assets.cpp:205-231)
+        std::vector<std::shared_ptr<image>> images{};
+        for(std::uint32_t k{0}; k < d->image_count; ++k) images.push_back(make_image(d->images[k]));
+
         for(std::uint32_t i{}; i < d->material_count; ++i)
         {
-            rs->materials.push_back(make_material(d->materials[i]));
+            rs->materials.push_back(make_material(*d, images, d->materials[i]));
             if(rs->materials.back() == nullptr) { delete rs; return nullptr; }
         }
         for(std::uint32_t i{}; i < d->medium_count; ++i)
@@ -435,10 +457,6 @@ extern "C"
             entities.push_back(std::move(ent));
         }
         rs->primitive_total = offset;
-
-        // images exactly as assets::load_image builds them from the raw file bytes (assets.cpp:205-231)
-        std::vector<std::shared_ptr<image>> images{};
-        for(std::uint32_t k{0}; k < d->image_count; ++k) images.push_back(make_image(d->images[k]));
 
         std::shared_ptr<infinity_area_light> env{};
         if(d->env_kind == FCGPU_ENV_CONST)
@@ -652,7 +670,10 @@ extern "C"
     int fcref_bsdf_table(fcgpu_material const* m, double const* ng, double const* tangent, double const* ns, double const* bitangent,
                          double eta_a, double eta_b, std::uint64_t n, fcref_bsdf_query const* q, fcref_bsdf_result* out)
     {
-        auto mat{make_material(*m)};
+        fcgpu_material constants{*m};  // the table is over one constant material: no image textures here
+        constants.tex_color_a = constants.tex_color_b = constants.tex_roughness = 0;
+        constants.tex_metalness = constants.tex_ior = constants.tex_normal = 0;
+        auto mat{make_material(fcgpu_scene_desc{}, {}, constants)};
         if(mat == nullptr) return -1;
         paged_allocator pages{1024 * 1024};
         allocator_wrapper al{&pages};

@@ -32,7 +32,13 @@ class Material(C.Structure):
         ("kind", C.c_int32), ("reserved", C.c_int32),
         ("color_a", c_double3), ("color_b", c_double3), ("roughness", c_double2),
         ("ior", C.c_double), ("metalness", C.c_double),
+        ("tex_color_a", C.c_int32), ("tex_color_b", C.c_int32), ("tex_roughness", C.c_int32),
+        ("tex_metalness", C.c_int32), ("tex_ior", C.c_int32), ("tex_normal", C.c_int32),
     ]
+
+
+class Texture(C.Structure):
+    _fields_ = [("image", C.c_int32), ("filter", C.c_int32)]
 
 
 class Medium(C.Structure):
@@ -83,6 +89,7 @@ class SceneDesc(C.Structure):
         ("camera", Camera),
         ("images", C.POINTER(Image)), ("image_count", C.c_uint32), ("reserved2", C.c_uint32),
         ("env_texture", EnvTexture),
+        ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32), ("reserved3", C.c_uint32),
     ]
 
 

@@ -130,23 +130,39 @@ namespace
         S.stack_spill = c->stack_spill;
         S.stack_spill_stride = static_cast<uint32_t>(c->grid) * 256u;
         S.envtex = EnvTex<R>{};
-        if(c->flat.env_kind == FCGPU_ENV_TEXTURE)
+        // decoded images -> texel arrays of this precision; image textures refer to them
+        std::vector<TexRef<R>> image_ref(c->flat.images.size());
+        for(size_t k = 0; k < c->flat.images.size(); ++k)
         {
-            const FlatEnvTexture& e = c->flat.env_texture;
-            const FlatImage& im = c->flat.images[e.image];
+            const FlatImage& im = c->flat.images[k];
             std::vector<Vec4<R>> texels(static_cast<size_t>(im.width) * im.height);
             for(size_t i = 0; i < texels.size(); ++i)
                 texels[i] = Vec4<R>{static_cast<R>(im.rgb[3 * i]), static_cast<R>(im.rgb[3 * i + 1]), static_cast<R>(im.rgb[3 * i + 2]), R(0)};
+            if((rc = upload(c, c->scene_allocs, texels, &image_ref[k].texels))) return rc;
+            image_ref[k].width = im.width;
+            image_ref[k].height = im.height;
+            image_ref[k].filter = FCGPU_FILTER_BILINEAR;
+        }
+        std::vector<TexRef<R>> tex_refs;
+        for(const auto& t : c->flat.textures)
+        {
+            TexRef<R> r = image_ref[t.first];
+            r.filter = t.second;
+            tex_refs.push_back(r);
+        }
+        if((rc = upload(c, c->scene_allocs, tex_refs, &S.textures))) return rc;
+        if((rc = upload(c, c->scene_allocs, T.matparams, &S.matparams))) return rc;
+        if(c->flat.env_kind == FCGPU_ENV_TEXTURE)
+        {
+            const FlatEnvTexture& e = c->flat.env_texture;
             EnvTex<R>& E = S.envtex;
-            if((rc = upload(c, c->scene_allocs, texels, &E.texels))) return rc;
+            E.tex = image_ref[e.image];
+            E.tex.filter = e.filter;
             if((rc = upload(c, c->scene_allocs, e.func_x, &E.func_x))) return rc;
             if((rc = upload(c, c->scene_allocs, e.cdf_x, &E.cdf_x))) return rc;
             if((rc = upload(c, c->scene_allocs, e.int_x, &E.int_x))) return rc;
             if((rc = upload(c, c->scene_allocs, e.func_y, &E.func_y))) return rc;
             if((rc = upload(c, c->scene_allocs, e.cdf_y, &E.cdf_y))) return rc;
-            E.width = im.width;
-            E.height = im.height;
-            E.filter = e.filter;
             E.nx = e.nx;
             E.ny = e.ny;
             E.strength = static_cast<R>(e.strength);

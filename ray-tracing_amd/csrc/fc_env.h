@@ -8,7 +8,7 @@
 
 namespace fcg
 {
-    template<typename R> FC_D vec3<R> tex_texel(const EnvTex<R>& E, int x, int y)
+    template<typename R> FC_D vec3<R> tex_texel(const TexRef<R>& E, int x, int y)
     {
         const Vec4<R> t = E.texels[static_cast<size_t>(E.width) * static_cast<size_t>(y) + static_cast<size_t>(x)];
         return vec3<R>{t.x, t.y, t.z};
@@ -17,7 +17,7 @@ namespace fcg
     FC_D int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
     // image_texture_2d_rgb::evaluate
-    template<typename R> FC_D vec3<R> tex_evaluate(const EnvTex<R>& E, R u, R v)
+    template<typename R> FC_D vec3<R> tex_evaluate(const TexRef<R>& E, R u, R v)
     {
         if(E.filter == FCGPU_FILTER_BILINEAR)
         {
@@ -89,7 +89,7 @@ namespace fcg
         if(S.env_kind != FCGPU_ENV_TEXTURE) return rgb(S.env);
         R u, v, theta;
         env_uv(S.envtex, wi, u, v, theta);
-        return tex_evaluate(S.envtex, u, v) * S.envtex.strength;
+        return tex_evaluate(S.envtex.tex, u, v) * S.envtex.strength;
     }
 
     // infinity_area_light::pdf_wi (solid angle)
@@ -131,7 +131,7 @@ namespace fcg
         const R phi = (R(1) - su) * R(2) * consts<R>::pi;
         const R cos_theta = r_cos(theta), sin_theta = r_sin(theta);
         if(sin_theta == R(0)) return false;
-        Li = tex_evaluate(E, su, sv) * E.strength;
+        Li = tex_evaluate(E.tex, su, sv) * E.strength;
         if(Li.x == R(0) && Li.y == R(0) && Li.z == R(0)) return false;
         const vec3<R> w{sin_theta * r_cos(phi), cos_theta, sin_theta * r_sin(phi)};
         wi = xf_dir(E.fwd, w);

@@ -11,6 +11,7 @@
 // std::nth_element / std::partition calls) and then collapsed into the 4-wide quantised
 // layout of fc_types.h, which is what the device traverses.
 #include "fc_host.h"
+#include "fc_material.h"
 
 #include <algorithm>
 #include <cmath>
@@ -554,96 +555,39 @@ namespace fcg
                 for(int j = 0; j < 4; ++j) dst[i * 4 + j] = static_cast<R>(m.m[i][j]);
         }
 
-        struct LobeD  // lobe in double, converted per precision
-        {
-            int type, fresnel;
-            double color[3], color2[3], alpha[2], ior, factor, cdf;
-        };
+        using LobeD = LobeRec<double>;  // lobe in double, converted per precision
 
-        double rough_to_alpha(double r)  // microfacet.hpp:76-81
+        MatValues<double> material_constants(const fcgpu_material& m)
         {
-            double x = std::max(r, 0.002);
-            return x * x;
+            MatValues<double> v{};
+            for(int i = 0; i < 3; ++i)
+            {
+                v.color_a[i] = m.color_a[i];
+                v.color_b[i] = m.color_b[i];
+            }
+            v.roughness[0] = m.roughness[0];
+            v.roughness[1] = m.roughness[1];
+            v.ior = m.ior;
+            v.metalness = m.metalness;
+            return v;
         }
 
-        // materials -> lobes, mirroring material::evaluate of each class with constant textures
+        // materials -> lobes through fc_material.h (material::evaluate of each class + the bsdf constructor);
+        // for a textured material the constants stand in, only to learn which lobe types it can produce
         int material_lobes(const fcgpu_material& m, std::vector<LobeD>& lobes, std::string& err)
         {
-            struct Pending
+            if(m.kind < FCGPU_MATERIAL_DIFFUSE || m.kind > FCGPU_MATERIAL_TRANSMISSION)
             {
-                LobeD lobe;
-                double scale, weight;
-            };
-            std::vector<Pending> ps;
-            auto base = [&](int type, int fresnel, const double* c, const double* c2, const double* rough, double ior)
-            {
-                LobeD l{};
-                l.type = type;
-                l.fresnel = fresnel;
-                for(int i = 0; i < 3; ++i)
-                {
-                    l.color[i] = c ? c[i] : 0.0;
-                    l.color2[i] = c2 ? c2[i] : 0.0;
-                }
-                l.alpha[0] = rough_to_alpha(rough ? rough[0] : 0.0);
-                l.alpha[1] = rough_to_alpha(rough ? rough[1] : 0.0);
-                l.ior = ior;
-                return l;
-            };
-            bool smooth = m.roughness[0] == 0.0 && m.roughness[1] == 0.0;
-            const double one[3]{1.0, 1.0, 1.0};
-            switch(m.kind)
-            {
-            case FCGPU_MATERIAL_DIFFUSE:  // diffuse_material.hpp:29-37
-                ps.push_back({base(L_LAMBERT, 0, m.color_a, nullptr, nullptr, 0.0), 1.0, 1.0});
-                break;
-            case FCGPU_MATERIAL_MIRROR:  // mirror_material.hpp:38-55
-                ps.push_back({base(smooth ? L_SPEC_REFL : L_GGX_REFL, 0, m.color_a, nullptr, m.roughness, 0.0), 1.0, 1.0});
-                break;
-            case FCGPU_MATERIAL_GLASS:  // glass_material.hpp:29-40
-                ps.push_back({base(smooth ? L_SPEC_GLASS : L_GGX_GLASS, 0, m.color_a, m.color_b, m.roughness, 0.0), 1.0, 1.0});
-                break;
-            case FCGPU_MATERIAL_PLASTIC:  // plastic_material.hpp:26-51
-                ps.push_back({base(L_LAMBERT, 0, m.color_a, nullptr, nullptr, 0.0), 1.0, 1.0});
-                ps.push_back({base(smooth ? L_SPEC_REFL : L_GGX_REFL, 1, m.color_b, nullptr, m.roughness, m.ior), 1.0, 1.0});
-                break;
-            case FCGPU_MATERIAL_STANDARD:  // standard_material.hpp:49-103
-            {
-                double r2[2]{m.roughness[0], m.roughness[0]};
-                bool sm = m.roughness[0] == 0.0;
-                if(m.metalness < 1.0)
-                {
-                    double s = 1.0 - m.metalness, w = (1.0 - m.metalness) / 2.0;
-                    ps.push_back({base(L_LAMBERT, 0, m.color_a, nullptr, nullptr, 0.0), s, w});
-                    ps.push_back({base(sm ? L_SPEC_REFL : L_GGX_REFL, 1, one, nullptr, r2, m.ior), s, w});
-                }
-                if(m.metalness > 0.0)
-                {
-                    ps.push_back({base(sm ? L_SPEC_REFL : L_GGX_REFL, 0, m.color_a, nullptr, r2, 0.0), m.metalness, m.metalness});
-                }
-                break;
-            }
-            case FCGPU_MATERIAL_TRANSMISSION:  // transmission_material.hpp:28-39
-                ps.push_back({base(smooth ? L_SPEC_TRANS : L_GGX_TRANS, 0, m.color_b, nullptr, m.roughness, 0.0), 1.0, 1.0});
-                break;
-            default:
                 err = "unknown material kind";
                 return FCGPU_E_INVALID;
             }
-            // bsdf constructor, bsdf.hpp:30-43
-            double weight_sum = 0.0;
-            for(auto& p : ps) weight_sum += p.weight;
-            double prefix = 0.0;
-            for(size_t i = 0; i < ps.size(); ++i)
-            {
-                double pdf = ps[i].weight / weight_sum;
-                ps[i].lobe.factor = ps[i].scale / pdf;
-                ps[i].lobe.cdf = i == 0 ? 0.0 : prefix;
-                // weight[i] = weight[i-1] + pdf[i-1], accumulated left to right as the reference does
-                prefix = (i == 0 ? 0.0 : prefix) + pdf;
-                lobes.push_back(ps[i].lobe);
-            }
-            return (int)ps.size();
+            const MatValues<double> v = material_constants(m);
+            int types[MAX_LOBES];
+            double scales[MAX_LOBES], weights[MAX_LOBES], factor[MAX_LOBES], cdf[MAX_LOBES];
+            const int n = material_layout(m.kind, v, types, scales, weights);
+            lobe_pick_table(n, scales, weights, factor, cdf);
+            for(int i = 0; i < n; ++i) lobes.push_back(material_lobe(m.kind, v, i, types[i], factor[i], cdf[i]));
+            return n;
         }
 
         template<typename R>
@@ -933,13 +877,83 @@ namespace fcg
         out.height = d.camera.height;
 
         // ---- materials
+        // image textures of material parameters (image_texture_2d_rgb / _r, textures/image_texture.hpp)
+        for(uint32_t i = 0; i < d.texture_count; ++i)
+        {
+            const fcgpu_texture& t = d.textures[i];
+            if(t.image < 0 || static_cast<uint32_t>(t.image) >= d.image_count || (t.filter != FCGPU_FILTER_BOX && t.filter != FCGPU_FILTER_BILINEAR))
+            {
+                err = "texture " + std::to_string(i) + ": image index or filter out of range";
+                return FCGPU_E_INVALID;
+            }
+            out.textures.emplace_back(t.image, t.filter);
+        }
         std::vector<LobeD> lobes;
         for(uint32_t i = 0; i < d.material_count; ++i)
         {
+            const fcgpu_material& m = d.materials[i];
             int first = static_cast<int>(lobes.size());
-            int n = material_lobes(d.materials[i], lobes, err);
+            int n = material_lobes(m, lobes, err);
             if(n < 0) return n;
-            out.materials.push_back(MaterialRec{first, n});
+            MaterialRec rec{};
+            rec.first_lobe = first;
+            rec.lobe_count = n;
+            rec.kind = m.kind;
+            if(m.tex_normal != 0)
+            {
+                err = "material " + std::to_string(i) + ": normal maps (tex_normal) are not supported";
+                return FCGPU_E_INVALID;
+            }
+            // which parameters each material class has (its constructor's texture arguments, src/materials/*.hpp);
+            // roughness is a texture_2d_rg everywhere but in standard_material and the reference has no rg image texture
+            const bool std_mat = m.kind == FCGPU_MATERIAL_STANDARD;
+            const bool allowed[5]{
+                m.kind != FCGPU_MATERIAL_TRANSMISSION,                                                                   // TEX_COLOR_A
+                m.kind == FCGPU_MATERIAL_GLASS || m.kind == FCGPU_MATERIAL_PLASTIC || m.kind == FCGPU_MATERIAL_TRANSMISSION,  // TEX_COLOR_B
+                std_mat,                                                                                                 // TEX_ROUGHNESS
+                std_mat,                                                                                                 // TEX_METALNESS
+                std_mat || m.kind == FCGPU_MATERIAL_PLASTIC,                                                             // TEX_IOR
+            };
+            const int32_t handles[5]{m.tex_color_a, m.tex_color_b, m.tex_roughness, m.tex_metalness, m.tex_ior};
+            for(int s = 0; s < 5; ++s)
+            {
+                if(handles[s] == 0) continue;
+                if(handles[s] < 0 || static_cast<uint32_t>(handles[s]) > d.texture_count || !allowed[s])
+                {
+                    err = "material " + std::to_string(i) + ": texture slot " + std::to_string(s) +
+                          (allowed[s] ? " names no texture" : " is not a texture parameter of this material class");
+                    return FCGPU_E_INVALID;
+                }
+                rec.tex[s] = handles[s];
+                rec.textured = 1;
+            }
+            if(rec.textured)
+            {
+                // lobe types are decided per hit: smooth vs rough by the roughness texel, the standard material's
+                // lobe set by its metalness texel
+                const bool rough_tex = rec.tex[TEX_ROUGHNESS] != 0;
+                const bool smooth_const = m.roughness[0] == 0.0 && (std_mat || m.roughness[1] == 0.0);
+                auto reflective = [&]() { out.lobe_mask |= (rough_tex || !smooth_const ? 1u << L_GGX_REFL : 0u) | (rough_tex || smooth_const ? 1u << L_SPEC_REFL : 0u); };
+                if(std_mat)
+                {
+                    out.lobe_mask |= 1u << L_LAMBERT;
+                    reflective();
+                }
+            }
+            out.materials.push_back(rec);
+            const MatValues<double> v = material_constants(m);
+            MatParam<float> vf{};
+            for(int k = 0; k < 3; ++k)
+            {
+                vf.color_a[k] = static_cast<float>(v.color_a[k]);
+                vf.color_b[k] = static_cast<float>(v.color_b[k]);
+            }
+            vf.roughness[0] = static_cast<float>(v.roughness[0]);
+            vf.roughness[1] = static_cast<float>(v.roughness[1]);
+            vf.ior = static_cast<float>(v.ior);
+            vf.metalness = static_cast<float>(v.metalness);
+            out.f32.matparams.push_back(vf);
+            out.f64.matparams.push_back(v);
         }
         for(const LobeD& l : lobes) out.lobe_mask |= 1u << l.type;
         convert_lobes(lobes, out.f32.lobes);

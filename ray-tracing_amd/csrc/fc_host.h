@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fcgpu.h"
@@ -29,6 +30,7 @@ namespace fcg
     {
         std::vector<XPrim<R>> xprims;
         std::vector<LobeRec<R>> lobes;
+        std::vector<MatParam<R>> matparams;
         std::vector<MediumRec<R>> media;
         std::vector<LightRec<R>> lights;
         CameraRec<R> camera{};
@@ -49,6 +51,7 @@ namespace fcg
         uint32_t light_count{};   // incl. the environment light when present (scene.hpp:66-70)
         int32_t env_kind{};
         std::vector<FlatImage> images;
+        std::vector<std::pair<int32_t, int32_t>> textures;  // (image, filter)
         FlatEnvTexture env_texture;
         uint32_t max_stack{};     // worst-case traversal stack depth of the wide BVH
         uint32_t binary_nodes{};

@@ -20,6 +20,7 @@
 #include "fc_bsdf.h"
 #include "fc_env.h"
 #include "fc_kernels.h"
+#include "fc_material.h"
 #include "fc_traverse.h"
 
 namespace fcg
@@ -212,6 +213,62 @@ namespace fcg
     // slowest ray of its wave ends; once FINISH_MIN lanes of the wave have finished (or nothing is
     // left to traverse) they resolve their hits together and take new rays (work_take).
 
+    // ------------------------------------------------------------------ textured materials
+    // surface_point::get_uv of a hit: mesh_surface.hpp:215-216 (+ :337-352 default uvs), plane_surface.hpp:91-95;
+    // sphere_surface never sets it (surface_point.hpp:50: {0, 0}). k_extend (lobe pick) and k_shade (lobe
+    // parameters) call this with the same stored p, b0, b1, so that both see the same texels.
+    template<typename R>
+    FC_D void surface_uv(const SceneDev<R>& S, uint32_t kind, uint32_t idx, vec3<R> p, R b0, R b1, R& u, R& v)
+    {
+        u = R(0);
+        v = R(0);
+        if(kind == KIND_TRI)
+        {
+            const uint32_t attr = S.tris[idx].attr;
+            const R b2 = R(1) - b0 - b1;
+            if(attr == INVALID_U32)
+            {
+                u = b0 * R(0) + b1 * R(1) + b2 * R(1);
+                v = b0 * R(0) + b1 * R(0) + b2 * R(1);
+            }
+            else
+            {
+                const TriAttr& A = S.tri_attrs[attr];
+                u = b0 * R(A.uv0[0]) + b1 * R(A.uv1[0]) + b2 * R(A.uv2[0]);
+                v = b0 * R(A.uv0[1]) + b1 * R(A.uv1[1]) + b2 * R(A.uv2[1]);
+            }
+        }
+        else if(kind == KIND_PLANE)
+        {
+            const XPrim<R>& P = S.xprims[idx];
+            const vec3<R> q = xf_point(P.inv, p);
+            u = (q.x + P.a / R(2)) / P.a;
+            v = R(1) - (q.z + P.b / R(2)) / P.b;
+        }
+    }
+
+    // the material's parameters at (u, v): image textures where it has them (x of the texel for the scalar
+    // ones, image_texture_2d_r), its constants elsewhere
+    template<typename R>
+    FC_D MatValues<R> material_values(const SceneDev<R>& S, uint32_t material, const MaterialRec& m, R u, R v)
+    {
+        MatValues<R> val = S.matparams[material];
+        if(m.tex[TEX_COLOR_A])
+        {
+            const vec3<R> c = tex_evaluate(S.textures[m.tex[TEX_COLOR_A] - 1], u, v);
+            val.color_a[0] = c.x, val.color_a[1] = c.y, val.color_a[2] = c.z;
+        }
+        if(m.tex[TEX_COLOR_B])
+        {
+            const vec3<R> c = tex_evaluate(S.textures[m.tex[TEX_COLOR_B] - 1], u, v);
+            val.color_b[0] = c.x, val.color_b[1] = c.y, val.color_b[2] = c.z;
+        }
+        if(m.tex[TEX_ROUGHNESS]) val.roughness[0] = val.roughness[1] = tex_evaluate(S.textures[m.tex[TEX_ROUGHNESS] - 1], u, v).x;
+        if(m.tex[TEX_METALNESS]) val.metalness = tex_evaluate(S.textures[m.tex[TEX_METALNESS] - 1], u, v).x;
+        if(m.tex[TEX_IOR]) val.ior = tex_evaluate(S.textures[m.tex[TEX_IOR] - 1], u, v).x;
+        return val;
+    }
+
     template<typename R, bool PROF, bool SPILL>
     __global__ __launch_bounds__(BLOCK) void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
@@ -325,15 +382,37 @@ namespace fcg
                                 const MaterialRec m = S.materials[S.entities[entity].material];
                                 uint64_t bits = fcgpu_stream_bits(&B.sampler, slot_stream(B, path), dim_lobe);
                                 double u = fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
-                                for(int l = m.lobe_count - 1; l >= 0; --l)
+                                if(m.textured)
                                 {
-                                    if(u > S.lobes[m.first_lobe + l].cdf)
+                                    R tu, tv;
+                                    surface_uv(S, T.pk >> 30, T.pk & 0x3FFFFFFFu, p, T.b0, T.b1, tu, tv);
+                                    const MatValues<R> val = material_values(S, S.entities[entity].material, m, tu, tv);
+                                    int types[MAX_LOBES];
+                                    double scales[MAX_LOBES], weights[MAX_LOBES], factor[MAX_LOBES], cdf[MAX_LOBES];
+                                    const int count = material_layout(m.kind, val, types, scales, weights);
+                                    lobe_pick_table(count, scales, weights, factor, cdf);
+                                    for(int l = count - 1; l >= 0; --l)
                                     {
-                                        lobe = static_cast<uint32_t>(l);
-                                        break;
+                                        if(u > cdf[l])
+                                        {
+                                            lobe = static_cast<uint32_t>(l);
+                                            break;
+                                        }
                                     }
+                                    key = types[lobe];
                                 }
-                                key = S.lobes[m.first_lobe + lobe].type;
+                                else
+                                {
+                                    for(int l = m.lobe_count - 1; l >= 0; --l)
+                                    {
+                                        if(u > S.lobes[m.first_lobe + l].cdf)
+                                        {
+                                            lobe = static_cast<uint32_t>(l);
+                                            break;
+                                        }
+                                    }
+                                    key = S.lobes[m.first_lobe + lobe].type;
+                                }
                             }
                             h0 = Vec4<R>{p.x, p.y, p.z, T.b0};
                             h1.x = T.b1;
@@ -673,7 +752,24 @@ namespace fcg
                     // ---- scatter at p1 := sp.p (forward_mis_integrator.hpp:47-112 / :153-168)
                     const vec3<R> w10 = -w12;
                     const MaterialRec mat = S.materials[ent.material];
-                    const LobeRec<R> L = S.lobes[mat.first_lobe + hit_word_lobe(hw)];
+                    LobeRec<R> L;
+                    if(mat.textured)
+                    {
+                        // material::evaluate at this hit's uv (fc_material.h); k_extend picked the lobe from the same values
+                        R tu, tv;
+                        surface_uv(S, hit_word_kind(hw), hit_word_index(hw), sp.p, h0.w, h1.x, tu, tv);
+                        const MatValues<R> val = material_values(S, static_cast<uint32_t>(ent.material), mat, tu, tv);
+                        int types[MAX_LOBES];
+                        double scales[MAX_LOBES], weights[MAX_LOBES], factor[MAX_LOBES], cdf[MAX_LOBES];
+                        const int count = material_layout(mat.kind, val, types, scales, weights);
+                        lobe_pick_table(count, scales, weights, factor, cdf);
+                        const int l = static_cast<int>(hit_word_lobe(hw));
+                        L = material_lobe(mat.kind, val, l, types[l], factor[l], cdf[l]);
+                    }
+                    else
+                    {
+                        L = S.lobes[mat.first_lobe + hit_word_lobe(hw)];
+                    }
                     const R eta_a = S.media[above].ior, eta_b = S.media[below].ior;
                     const fcgpu_sample_stream key = slot_stream(B, path);
                     constexpr bool DELTA = KEY == L_SPEC_REFL || KEY == L_SPEC_GLASS || KEY == L_SPEC_TRANS;
@@ -750,8 +846,18 @@ namespace fcg
                     draw(B, key, dim_u2, u2x, u2y);
                     draw(B, key, dim_u1, u1x, u1y);
                     vec3<R> value;
+#ifdef FCG_DEBUG_PRINT
+                    printf("shade key %d h %d path %u hw %08x textured %d p %.9g %.9g %.9g b %.9g %.9g | L type %d fr %d c %.6g %.6g %.6g c2 %.6g %.6g %.6g a %.6g %.6g ior %.6g fac %.6g | eta %.6g %.6g u1 %.9g %.9g u2 %.9g %.9g w10 %.9g %.9g %.9g\n",
+                           KEY, B.h, path, hw, mat.textured, (double)sp.p.x, (double)sp.p.y, (double)sp.p.z, (double)h0.w, (double)h1.x, L.type, L.fresnel,
+                           (double)L.color[0], (double)L.color[1], (double)L.color[2], (double)L.color2[0], (double)L.color2[1], (double)L.color2[2],
+                           (double)L.alpha[0], (double)L.alpha[1], (double)L.ior, (double)L.factor, (double)eta_a, (double)eta_b, (double)u1x, (double)u1y,
+                           (double)u2x, (double)u2y, (double)w10.x, (double)w10.y, (double)w10.z);
+#endif
                     if(bsdf_sample_wi<KEY>(L, sp.f, w10, eta_a, eta_b, u1x, u1y, u2x, u2y, wn, value, pdf_w12))
                     {
+#ifdef FCG_DEBUG_PRINT
+                        printf("   -> wn %.9g %.9g %.9g value %.6g %.6g %.6g pdf %.6g\n", (double)wn.x, (double)wn.y, (double)wn.z, (double)value.x, (double)value.y, (double)value.z, (double)pdf_w12);
+#endif
                         beta = beta * (value * (r_abs(dot(ng, wn)) / pdf_w12));  // :112
                         alive = true;
                         // helper::raycast entry: leaving p into its own medium pushes it, integrator.hpp:36-44

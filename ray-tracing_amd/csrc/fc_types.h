@@ -123,8 +123,29 @@ namespace fcg
 
     struct MaterialRec
     {
-        int32_t first_lobe;
+        int32_t first_lobe;   // constant materials: their lobes are precomputed (lobes[first_lobe ..])
         int32_t lobe_count;
+        int32_t kind;         // FCGPU_MATERIAL_*
+        int32_t textured;     // 1 = some parameter is an image texture: lobes are built per hit (fc_material.h)
+        int32_t tex[5];       // TEX_* slots: 0 = constant, k > 0 = textures[k - 1]
+        int32_t pad;
+    };
+    enum TexSlot { TEX_COLOR_A = 0, TEX_COLOR_B = 1, TEX_ROUGHNESS = 2, TEX_METALNESS = 3, TEX_IOR = 4 };
+
+    template<typename R>
+    struct MatParam  // the constants of fcgpu_material, by material
+    {
+        R color_a[3], color_b[3], roughness[2], ior, metalness;
+    };
+
+    template<typename R> struct Vec4;
+    template<typename R>
+    struct TexRef  // image_texture_2d_*: decoded texels of image::rgb() + reconstruction filter
+    {
+        const Vec4<R>* texels;  // row-major, top row first
+        int32_t width, height;
+        int32_t filter;         // FCGPU_FILTER_*
+        int32_t pad;
     };
 
     constexpr int MAX_MEDIA = 15;       // 4-bit medium ids, 0 = vacuum
@@ -155,15 +176,11 @@ namespace fcg
     // texture_infinity_area_light (texture_infinity_area_light.hpp:15-131): the image texture
     // (decoded texels, image_texture.hpp:88-124) and its radiance distribution (distribution.hpp:
     // 23-166; kept in double like the light CDFs so that discrete picks equal the reference's).
-    template<typename R> struct Vec4;
     template<typename R>
     struct EnvTex
     {
-        const Vec4<R>* texels;    // rgb of image::rgb(), row-major, top row first
-        int32_t width, height;
-        int32_t filter;           // FCGPU_FILTER_*
+        TexRef<R> tex;
         int32_t nx, ny;           // distribution resolution
-        int32_t pad;
         R strength;
         R fwd[12], inv[12];       // the light's pr_transform (rotation only) and its inverse
         const double* func_x;     // [ny][nx]   row functions (luminance(integral) * sin theta), after distribution_1d's zero-row rule
@@ -194,6 +211,8 @@ namespace fcg
         const EntityRec* entities;
         const MaterialRec* materials;
         const LobeRec<R>* lobes;
+        const MatParam<R>* matparams;
+        const TexRef<R>* textures;
         const MediumRec<R>* media;
         const LightRec<R>* lights;
         const double* light_cdf;

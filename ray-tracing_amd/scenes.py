@@ -25,6 +25,7 @@ class Scene:
         self.env_kind = A.ENV_NONE
         self.env_color = (0.0, 0.0, 0.0)
         self.images = []          # (format id, contiguous pixel array of shape (height, width, channels))
+        self.textures = []        # A.Texture: image textures usable as material parameters
         self.env_texture = A.EnvTexture()
         self._keep = None
 
@@ -68,8 +69,10 @@ class Scene:
         return len(self.surfaces) - 1
 
     # ---- materials / media
-    def material(self, kind, color_a=(0, 0, 0), color_b=(0, 0, 0), roughness=(0, 0), ior=1.0, metalness=0.0):
-        m = A.Material(kind=kind, ior=ior, metalness=metalness)
+    def material(self, kind, color_a=(0, 0, 0), color_b=(0, 0, 0), roughness=(0, 0), ior=1.0, metalness=0.0, **tex):
+        """`tex`: tex_color_a / tex_color_b / tex_roughness / tex_metalness / tex_ior = handles from texture()
+        that replace the constant of the same name (see fcgpu_material)."""
+        m = A.Material(kind=kind, ior=ior, metalness=metalness, **tex)
         m.color_a[:] = color_a
         m.color_b[:] = color_b
         m.roughness[:] = roughness
@@ -131,6 +134,12 @@ class Scene:
         self.images.append((A.IMAGE_FORMAT_IDS[fmt], np.ascontiguousarray(px)))
         return len(self.images) - 1
 
+    def texture(self, image, filter="bilinear"):
+        """image_texture_2d_rgb / image_texture_2d_r over `image`; returns the handle to pass as a material's
+        tex_* argument (1-based: 0 means "use the constant")."""
+        self.textures.append(A.Texture(image=image, filter=A.FILTER_BILINEAR if filter == "bilinear" else A.FILTER_BOX))
+        return len(self.textures)
+
     def set_env_texture(self, image, strength=1.0, rotation=(0, 0, 0), filter="bilinear", integral_sample_count=4,
                         distribution_resolution=None):
         """texture_infinity_area_light{{{}, rotation}, image_texture_2d_rgb{image, filter, integral_sample_count},
@@ -183,7 +192,10 @@ class Scene:
         d.images = imgs
         d.image_count = len(self.images)
         d.env_texture = self.env_texture
-        self._keep = (surf, mats, meds, ents, pos, nrm, uv, idx, imgs)
+        texs = (A.Texture * max(1, len(self.textures)))(*self.textures)
+        d.textures = texs
+        d.texture_count = len(self.textures)
+        self._keep = (surf, mats, meds, ents, pos, nrm, uv, idx, imgs, texs)
         return d
 
 
@@ -448,5 +460,62 @@ def env_texture_scene(width=96, height=64, fmt="rgb32", filter="bilinear", lens=
     return sc
 
 
+def pattern_image(width, height, fmt, seed=0, lo=0.0, hi=1.0):
+    """A deterministic blocky test pattern (checker + per-cell noise) in any image format; rgb32 values lie
+    in [lo, hi], byte formats use the full 0..255 range (incl. exact 0 and 255)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    checker = ((x // 2 + y // 2) % 2).astype(np.float64)
+    ch = 1 if fmt == "r8" else 3
+    val = np.clip(0.15 + 0.7 * checker[:, :, None] + rng.uniform(-0.15, 0.15, (height, width, ch)), 0.0, 1.0)
+    if fmt == "rgb32":
+        return (lo + (hi - lo) * val).astype(np.float32)
+    byte = np.round(255.0 * val).astype(np.uint8)
+    byte[0::3, 0::4] = 0      # exact zeros / ones: a roughness texel of 0 switches to the specular lobe,
+    byte[1::3, 2::4] = 255    # a metalness texel of 1 drops the dielectric lobes (standard_material.hpp:49,89)
+    return byte[:, :, 0] if fmt == "r8" else byte
+
+
+def textured_scene(width=96, height=64):
+    """Image textures on material parameters (image_texture_2d_rgb / image_texture_2d_r): every material class
+    with at least one textured parameter, on a plane (plane uvs), a mesh with uvs, a mesh without (default uvs)
+    and spheres (uv = (0, 0)); box and bilinear filters; all four image formats."""
+    sc = Scene()
+    checker = sc.texture(sc.image(pattern_image(16, 16, "rgb8", 1), "rgb8"), "box")
+    soft = sc.texture(sc.image(pattern_image(8, 8, "srgb8", 2), "srgb8"), "bilinear")
+    hdr = sc.texture(sc.image(pattern_image(8, 4, "rgb32", 3, 0.2, 0.95), "rgb32"), "bilinear")
+    ior_map = sc.texture(sc.image(pattern_image(4, 4, "rgb32", 4, 1.3, 1.8), "rgb32"), "box")
+    rough_map = sc.texture(sc.image(pattern_image(12, 6, "r8", 5), "r8"), "box")
+    metal_map = sc.texture(sc.image(pattern_image(6, 6, "r8", 6), "r8"), "bilinear")
+    metal_box = sc.texture(sc.image(pattern_image(5, 7, "r8", 7), "r8"), "box")
+
+    sc.entity(sc.plane((0, 0, 0), (16, 16)), sc.material(A.MATERIAL_DIFFUSE, tex_color_a=checker))
+    sc.entity(sc.plane((0, 4, -6), (16, 8), (math.radians(90), 0, 0)),
+              sc.material(A.MATERIAL_PLASTIC, color_b=(1, 1, 1), roughness=(0.3, 0.1), tex_color_a=soft, tex_ior=ior_map))
+    nu, nv = 12, 8
+    th, ph = np.meshgrid(np.linspace(0, math.pi, nv + 1), np.linspace(0, 2 * math.pi, nu + 1), indexing="ij")
+    p = np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3)
+    uv = np.stack([ph / (2 * math.pi), th / math.pi], -1).reshape(-1, 2)
+    i, j = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    a = (i * (nu + 1) + j).reshape(-1)
+    b, c, d = a + (nu + 1), a + (nu + 2), a + 1
+    tris = np.stack([a, c, b, a, d, c], 1).reshape(-1)  # wound so that geometric normals point outwards like the vertex normals
+    sc.entity(sc.mesh(p, tris, normals=p.copy(), uvs=uv, position=(-2.5, 1.3, 0.5), rotation=(0.3, 0.5, 0.1), scale=(1.3, 1.3, 1.3)),
+              sc.material(A.MATERIAL_STANDARD, ior=1.45, tex_color_a=hdr, tex_metalness=metal_map, tex_roughness=rough_map))
+    sc.entity(sc.mesh(p, tris, uvs=uv, position=(2.6, 1.1, 1.6), scale=(1.1, 1.1, 1.1)),
+              sc.material(A.MATERIAL_STANDARD, color_a=(0.8, 0.7, 0.3), roughness=(0.25, 0.25), tex_metalness=metal_box, tex_ior=ior_map))
+    bp, bi = box_outward((-0.7, 0.0, -0.7), (0.7, 1.4, 0.7))
+    sc.entity(sc.mesh(bp, bi, position=(0.3, 0.02, 2.6), rotation=(0, 0.6, 0)),  # off the floor: no coplanar faces (exact t ties)
+              sc.material(A.MATERIAL_GLASS, roughness=(0.0, 0.0), tex_color_a=soft, tex_color_b=hdr), medium=sc.medium(1, 1.5, (0.9, 0.6, 0.4), 0.3))
+    sc.entity(sc.sphere((0.4, 1.0, -1.5), 1.0, (0.2, 0.7, 0.4)), sc.material(A.MATERIAL_MIRROR, roughness=(0.15, 0.05), tex_color_a=hdr))
+    sc.entity(sc.mesh(bp, bi, position=(4.6, 0.03, -1.5), rotation=(0, -0.4, 0), scale=(1.2, 1.5, 1.2)),
+              sc.material(A.MATERIAL_TRANSMISSION, roughness=(0.2, 0.2), tex_color_b=checker), medium=sc.medium(1, 1.33, (0.3, 0.5, 0.9), 0.2))
+    qp, qi = grid_quad((-1.0, 5.0, -1.0), (2.0, 0, 0), (0, 0, 2.0), 2, 2)
+    sc.entity(sc.mesh(qp, qi), sc.diffuse((0.1, 0.1, 0.1)), emission=(1.0, 0.95, 0.9), strength=20.0)
+    sc.set_env((0.3, 0.35, 0.45))
+    sc.set_camera((0.0, 3.2, 9.5), (math.radians(12.0), math.radians(180.0), 0.0), math.radians(42.0), width, height)
+    return sc
+
+
 BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo,
-            "env_texture_scene": env_texture_scene}
+            "env_texture_scene": env_texture_scene, "textured_scene": textured_scene}

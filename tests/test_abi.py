@@ -27,13 +27,30 @@ def test_struct_layouts_match_header():
     # sizes the C compiler produced are asserted in the library by static_asserts on the device
     # structs; the public PODs are checked here against hand-counted layouts
     assert C.sizeof(A.Surface) == 16 + 9 * 8 + 8 + 16 + 16
-    assert C.sizeof(A.Material) == 8 + 10 * 8
+    assert C.sizeof(A.Material) == 8 + 10 * 8 + 6 * 4
+    assert C.sizeof(A.Texture) == 8
     assert C.sizeof(A.Medium) == 8 + 5 * 8
     assert C.sizeof(A.Entity) == 16 + 4 * 8
     assert C.sizeof(A.Camera) == 9 * 8 + 8
     assert C.sizeof(A.Ray) == 56 and C.sizeof(A.Hit) == 32
     assert C.sizeof(A.Counters) == 16 * 8
     assert C.sizeof(A.Options) == 24
+
+
+def test_struct_sizes_equal_what_the_c_compiler_sees(tmp_path):
+    """sizeof of every public POD as gcc lays it out from include/fcgpu.h == the ctypes mirror's."""
+    import subprocess
+    pairs = [("fcgpu_surface", A.Surface), ("fcgpu_material", A.Material), ("fcgpu_texture", A.Texture), ("fcgpu_medium", A.Medium),
+             ("fcgpu_entity", A.Entity), ("fcgpu_camera", A.Camera), ("fcgpu_image", A.Image), ("fcgpu_env_texture", A.EnvTexture),
+             ("fcgpu_scene_desc", A.SceneDesc), ("fcgpu_options", A.Options), ("fcgpu_tile", A.Tile), ("fcgpu_ray", A.Ray),
+             ("fcgpu_hit", A.Hit), ("fcgpu_counters", A.Counters), ("fcgpu_stage_times", A.StageTimes)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "fcgpu.h"\nint main(void){' +
+                   "".join(f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) + "return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert sizes == [C.sizeof(t) for _, t in pairs], list(zip([c for c, _ in pairs], sizes, [C.sizeof(t) for _, t in pairs]))
 
 
 def test_no_cpu_fallback(monkeypatch):

@@ -127,6 +127,20 @@ def test_error_codes():
         with pytest.raises(R.FcgpuError) as e:
             ctx.upload_scene(bad)
         assert e.value.code == A.E_INVALID
+    # image textures of materials: handle range, parameters the material class does not have, normal maps
+    for index, field, value in ((0, "tex_color_a", 99), (0, "tex_color_a", -1), (0, "tex_roughness", 1), (5, "tex_color_b", 1),
+                                (6, "tex_color_a", 1), (2, "tex_normal", 1)):
+        bad = S.textured_scene(16, 12)
+        setattr(bad.materials[index], field, value)
+        with pytest.raises(R.FcgpuError) as e:
+            ctx.upload_scene(bad)
+        assert e.value.code == A.E_INVALID, (index, field)
+        assert b"material" in lib.fcgpu_last_error(ctx.h)
+    bad = S.textured_scene(16, 12)
+    bad.textures[0].image = 77
+    with pytest.raises(R.FcgpuError) as e:
+        ctx.upload_scene(bad)
+    assert e.value.code == A.E_INVALID
     with pytest.raises(R.FcgpuError) as e:
         ctx.set_sampler(0, stratified=0)
     assert e.value.code == A.E_INVALID
@@ -265,3 +279,39 @@ def test_deep_bvh_spills_the_traversal_stack_and_still_matches_the_oracle():
 def pixel_rel_err_max(a, b):
     from common import pixel_rel_err
     return float(pixel_rel_err(a, b).max())
+
+
+def test_textured_material_with_uniform_images_equals_its_constant_twin():
+    """Image textures whose texels all hold one value must render exactly what the constant material
+    renders (same lobes, same sample stream): per-hit lobe construction == upload-time precompute.
+    All parameter values are dyadic so that fp32 and fp64 parameter arithmetic agree to the bit."""
+    def build(textured):
+        sc = S.Scene()
+        flat = lambda c: np.broadcast_to(np.asarray(c, np.float32), (3, 5, 3)).copy()
+        tex = (lambda c: sc.texture(sc.image(flat(c), "rgb32"), "box")) if textured else None  # box: texel values come back exactly
+        def mat(kind, **kw):
+            names = {"color_a": "tex_color_a", "color_b": "tex_color_b", "ior": "tex_ior", "metalness": "tex_metalness"}
+            args, texargs = dict(kw), {}
+            if textured:
+                for k, v in kw.items():
+                    if k in names and not (k == "ior" and kind not in (A.MATERIAL_PLASTIC, A.MATERIAL_STANDARD)):
+                        texargs[names[k]] = tex(v if k.startswith("color") else (v, 0, 0))
+                if kind == A.MATERIAL_STANDARD:
+                    texargs["tex_roughness"] = tex((kw["roughness"][0], 0, 0))
+            return sc.material(kind, **args, **texargs)
+        sc.entity(sc.plane((0, 0, 0), (16, 16)), mat(A.MATERIAL_DIFFUSE, color_a=(0.25, 0.5, 0.75)))
+        sc.entity(sc.plane((0, 4, -6), (16, 8), (np.pi / 2, 0, 0)),
+                  mat(A.MATERIAL_PLASTIC, color_a=(0.5, 0.25, 0.125), color_b=(1, 1, 1), roughness=(0.25, 0.125), ior=1.5))
+        sc.entity(sc.sphere((-2.5, 1.2, 0.5), 1.2), mat(A.MATERIAL_STANDARD, color_a=(0.75, 0.5, 0.25), roughness=(0.25, 0.25), ior=1.5, metalness=0.5))
+        sc.entity(sc.sphere((2.5, 1.0, 1.0), 1.0), mat(A.MATERIAL_STANDARD, color_a=(0.75, 0.75, 0.25), roughness=(0.0, 0.0), ior=1.25, metalness=1.0))
+        sc.entity(sc.sphere((0.2, 0.9, 2.2), 0.9), mat(A.MATERIAL_GLASS, color_a=(1, 1, 1), color_b=(0.5, 1, 0.75), roughness=(0.0, 0.0)),
+                  medium=sc.medium(1, 1.5, (0.9, 0.6, 0.4), 0.3))
+        sc.entity(sc.sphere((0.0, 5.0, 0.0), 0.7), sc.diffuse((0.1, 0.1, 0.1)), emission=(1, 1, 1), strength=15.0)
+        sc.set_env((0.3, 0.35, 0.45))
+        sc.set_camera((0.0, 3.2, 9.5), (np.radians(12.0), np.radians(180.0), 0.0), np.radians(42.0), 64, 40)
+        return sc
+    for precision in ("f64", "f32"):
+        a, na, _ = render(build(False), spp=8, seed=5, precision=precision)
+        b, nb, _ = render(build(True), spp=8, seed=5, precision=precision)
+        assert na == nb and a.mean() > 0
+        assert np.array_equal(a, b), precision

@@ -48,7 +48,11 @@ def test_hits_match_reference(oracle, name):
 def test_bsdf_tables_match_reference(oracle):
     z = np.load(os.path.join(GOLDEN, "bsdf_tables.npz"))
     names = [str(n) for n in z["material_names"]]
-    mats = np.frombuffer(z["materials"].tobytes(), dtype=np.uint8).reshape(len(names), C.sizeof(A.Material))
+    # the fixture holds fcgpu_material records as they were when it was written (the tex_* handles were appended
+    # later: zero = constant parameter, which is what the tables are about)
+    stored = np.frombuffer(z["materials"].tobytes(), dtype=np.uint8).reshape(len(names), -1)
+    mats = np.zeros((len(names), C.sizeof(A.Material)), np.uint8)
+    mats[:, : stored.shape[1]] = stored
     q = z["queries"]
     checked = 0
     for mi, name in enumerate(names):
