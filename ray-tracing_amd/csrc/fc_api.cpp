@@ -129,6 +129,8 @@ namespace
         S.env_kind = c->flat.env_kind;
         S.stack_spill = c->stack_spill;
         S.stack_spill_stride = static_cast<uint32_t>(c->grid) * 256u;
+        S.textured_materials = 0;
+        for(const MaterialRec& m : c->flat.materials) S.textured_materials |= static_cast<uint32_t>(m.textured);
         S.envtex = EnvTex<R>{};
         // decoded images -> texel arrays of this precision; image textures refer to them
         std::vector<TexRef<R>> image_ref(c->flat.images.size());

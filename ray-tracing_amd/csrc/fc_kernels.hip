@@ -269,7 +269,9 @@ namespace fcg
         return val;
     }
 
-    template<typename R, bool PROF, bool SPILL>
+    // TEX: the scene has materials with image textures (per-hit lobe construction compiled in: +5 % shade time, so
+    // scenes without them run the instantiations without it)
+    template<typename R, bool PROF, bool SPILL, bool TEX>
     __global__ __launch_bounds__(BLOCK) void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};  // PROF: descent, leaf cycles, trips, leaf phases, finish cycles, finish phases
@@ -382,7 +384,7 @@ namespace fcg
                                 const MaterialRec m = S.materials[S.entities[entity].material];
                                 uint64_t bits = fcgpu_stream_bits(&B.sampler, slot_stream(B, path), dim_lobe);
                                 double u = fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
-                                if(m.textured)
+                                if(TEX && m.textured)
                                 {
                                     R tu, tv;
                                     surface_uv(S, T.pk >> 30, T.pk & 0x3FFFFFFFu, p, T.b0, T.b1, tu, tv);
@@ -677,7 +679,7 @@ namespace fcg
     // ------------------------------------------------------------------ shade
     // KEY in [0, L_COUNT): a path arrives at a hit, then scatters with lobe type KEY.
     // KEY == Q_FINAL: the last vertex (path length == max_path_length): arrival terms only.
-    template<typename R, int KEY>
+    template<typename R, int KEY, bool TEX>
     __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         __shared__ uint32_t q_lds[2][WAVES];
@@ -753,7 +755,7 @@ namespace fcg
                     const vec3<R> w10 = -w12;
                     const MaterialRec mat = S.materials[ent.material];
                     LobeRec<R> L;
-                    if(mat.textured)
+                    if(TEX && mat.textured)
                     {
                         // material::evaluate at this hit's uv (fc_material.h); k_extend picked the lobe from the same values
                         R tu, tv;
@@ -1108,34 +1110,53 @@ namespace fcg
     }
     template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
-        // SPILL variants only for scenes whose BVH needs more stack than the LDS holds (S.stack_spill set at upload)
-        if(S.stack_spill)
-            hipLaunchKernelGGL((k_extend<R, false, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
+        // SPILL variants only for scenes whose BVH needs more stack than the LDS holds (S.stack_spill set at upload),
+        // TEX variants only for scenes with textured materials
+        const dim3 g(L.grid), b(BLOCK);
+        if(S.textured_materials)
+        {
+            if(S.stack_spill)
+                hipLaunchKernelGGL((k_extend<R, false, true, true>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
+            else
+                hipLaunchKernelGGL((k_extend<R, false, false, true>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
+        }
+        else if(S.stack_spill)
+            hipLaunchKernelGGL((k_extend<R, false, true, false>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
         else if(Q.timeline)
-            hipLaunchKernelGGL((k_extend<R, true, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
+            hipLaunchKernelGGL((k_extend<R, true, false, false>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
         else
-            hipLaunchKernelGGL((k_extend<R, false, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_extend, L.stream, S, Q, B);
+            hipLaunchKernelGGL((k_extend<R, false, false, false>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
     }
     template<typename R> void launch_sort(const LaunchCfg& L, const Wavefront<R>& Q, const Batch& B)
     {
         hipLaunchKernelGGL(k_sort<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, Q, B);
     }
-    template<typename R> void launch_shade(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key)
+    template<typename R, bool TEX> void launch_shade_lobe(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key)
     {
-        dim3 g(L.grid), b(BLOCK);
+        const dim3 g(L.grid), b(BLOCK);
         switch(key)
         {
-        case L_LAMBERT: hipLaunchKernelGGL((k_shade<R, L_LAMBERT>), g, b, 0, L.stream, S, Q, B); break;
-        case L_GGX_REFL: hipLaunchKernelGGL((k_shade<R, L_GGX_REFL>), g, b, 0, L.stream, S, Q, B); break;
-        case L_SPEC_REFL: hipLaunchKernelGGL((k_shade<R, L_SPEC_REFL>), g, b, 0, L.stream, S, Q, B); break;
-        case L_GGX_GLASS: hipLaunchKernelGGL((k_shade<R, L_GGX_GLASS>), g, b, 0, L.stream, S, Q, B); break;
-        case L_SPEC_GLASS: hipLaunchKernelGGL((k_shade<R, L_SPEC_GLASS>), g, b, 0, L.stream, S, Q, B); break;
-        case L_GGX_TRANS: hipLaunchKernelGGL((k_shade<R, L_GGX_TRANS>), g, b, 0, L.stream, S, Q, B); break;
-        case L_SPEC_TRANS: hipLaunchKernelGGL((k_shade<R, L_SPEC_TRANS>), g, b, 0, L.stream, S, Q, B); break;
-        case Q_FINAL: hipLaunchKernelGGL((k_shade<R, Q_FINAL>), g, b, 0, L.stream, S, Q, B); break;
-        case Q_MISS: hipLaunchKernelGGL(k_miss<R>, g, b, 0, L.stream, S, Q, B); break;
+        case L_LAMBERT: hipLaunchKernelGGL((k_shade<R, L_LAMBERT, TEX>), g, b, 0, L.stream, S, Q, B); break;
+        case L_GGX_REFL: hipLaunchKernelGGL((k_shade<R, L_GGX_REFL, TEX>), g, b, 0, L.stream, S, Q, B); break;
+        case L_SPEC_REFL: hipLaunchKernelGGL((k_shade<R, L_SPEC_REFL, TEX>), g, b, 0, L.stream, S, Q, B); break;
+        case L_GGX_GLASS: hipLaunchKernelGGL((k_shade<R, L_GGX_GLASS, TEX>), g, b, 0, L.stream, S, Q, B); break;
+        case L_SPEC_GLASS: hipLaunchKernelGGL((k_shade<R, L_SPEC_GLASS, TEX>), g, b, 0, L.stream, S, Q, B); break;
+        case L_GGX_TRANS: hipLaunchKernelGGL((k_shade<R, L_GGX_TRANS, TEX>), g, b, 0, L.stream, S, Q, B); break;
+        case L_SPEC_TRANS: hipLaunchKernelGGL((k_shade<R, L_SPEC_TRANS, TEX>), g, b, 0, L.stream, S, Q, B); break;
         default: break;
         }
+    }
+    template<typename R> void launch_shade(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key)
+    {
+        const dim3 g(L.grid), b(BLOCK);
+        if(key == Q_FINAL)
+            hipLaunchKernelGGL((k_shade<R, Q_FINAL, false>), g, b, 0, L.stream, S, Q, B);  // arrival terms only: no lobe is built
+        else if(key == Q_MISS)
+            hipLaunchKernelGGL(k_miss<R>, g, b, 0, L.stream, S, Q, B);
+        else if(S.textured_materials)
+            launch_shade_lobe<R, true>(L, S, Q, B, key);
+        else
+            launch_shade_lobe<R, false>(L, S, Q, B, key);
     }
     template<typename R> void launch_shadow(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {

@@ -218,7 +218,7 @@ namespace fcg
         const double* light_cdf;
         uint32_t* stack_spill;     // [depth - STACK_CAP][grid lanes] or nullptr when the BVH fits the LDS stack
         uint32_t stack_spill_stride;
-        uint32_t stack_spill_pad;
+        uint32_t textured_materials;  // 1 = some material has image textures (selects the TEX kernel instantiations)
         CameraRec<R> camera;
         uint32_t light_count;
         int32_t env_kind;
