@@ -85,8 +85,10 @@ typedef struct fcgpu_material {
      * rgb parameters: color_a, color_b (every material). Single-channel parameters (.r of the image):
      * ior (PLASTIC, STANDARD), metalness and roughness (STANDARD: its roughness is one texture_2d_r).
      * The two-channel roughness of the other materials is a texture_2d_rg, for which the reference
-     * has no image class: constants only. tex_normal (normal maps) is not implemented yet:
-     * FCGPU_E_INVALID when set. */
+     * has no image class: constants only. tex_normal: the normal map of DIFFUSE, MIRROR and STANDARD
+     * (their lobes then sit inside normal_mapping<T>, bsdfs/normal_mapping.hpp); an rgb texture holding
+     * a tangent-space normal as n * 0.5 + 0.5 with blue = up (diffuse_material.hpp:20-27). A handle on a
+     * parameter the material class does not have gives FCGPU_E_INVALID. */
     int32_t tex_color_a;
     int32_t tex_color_b;
     int32_t tex_roughness;

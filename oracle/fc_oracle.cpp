@@ -1336,6 +1336,27 @@ namespace fco
             if(m.tex_metalness > 0) m.metalness = static_cast<double>(tex(m.tex_metalness).x);
             if(m.tex_ior > 0) m.ior = static_cast<double>(tex(m.tex_ior).x);
         }
+        // the normal map of diffuse / mirror / standard materials (diffuse_material.hpp:20-27, mirror_material.hpp:29-36,
+        // standard_material.hpp:39-46) and normal_mapping's precompute (normal_mapping.hpp:743-760)
+        NormalMap<R> nm{};
+        if(scene && m.tex_normal > 0)
+        {
+            const fcgpu_texture& t = scene->textures[static_cast<size_t>(m.tex_normal - 1)];
+            V3<R> c = image_evaluate<R>(scene->images[static_cast<size_t>(t.image)], t.filter, p.u, p.v);
+            V3<R> n = c * R(2) - V3<R>{R(1), R(1), R(1)};
+            std::swap(n.y, n.z);
+            n = normalize(n);
+            if(n.y < R(0)) n = -n;
+            if(!(std::abs(n.x) < R(0.001) && std::abs(n.z) < R(0.001)))
+            {
+                nm.on = true;
+                nm.p = n;
+                nm.t = normalize(V3<R>{-n.x, R(0), -n.z});
+                nm.bitangent = normalize(cross(V3<R>{R(1), R(0), R(0)}, n));
+                nm.tangent = cross(n, nm.bitangent);
+            }
+        }
+        const bool maps_normals = m.kind == FCGPU_MATERIAL_DIFFUSE || m.kind == FCGPU_MATERIAL_MIRROR || m.kind == FCGPU_MATERIAL_STANDARD;
         Bsdf<R> b;
         b.t = p.tangent;
         b.ns = p.shading_normal;
@@ -1351,6 +1372,7 @@ namespace fco
         auto add = [&](LobeKind kind, bool fd, V3<R> refl, V3<R> trans, double rx, double ry, double ior, double scale, double weight)
         {
             Lobe<R>& L = b.lobes[b.count];
+            if(maps_normals) L.nm = nm;
             L.kind = kind;
             L.fresnel_dielectric = fd;
             L.reflectance = refl;
@@ -1412,6 +1434,113 @@ namespace fco
         return b;
     }
 
+    // ---------------------------------------------------------------- normal_mapping<T>, bsdfs/normal_mapping.hpp
+    // Light travels i -> (facets) -> o along at most three routes (second-order scattering):
+    //   P  : meets the mapped facet, scatters by the inner bxdf straight to o            f(i, o)
+    //   TP : meets the tangent facet first, is mirrored (ri), then scatters on p to o     f(ri, o)
+    //   PT : scatters on p towards ro, the mirror image of o, and the tangent facet turns it into o   f(i, ro)
+    // evaluate (:32-145), pdf (:629-731) and sample (:147-626) enumerate the 3x3 facet classes of (i, o); the sums
+    // below are those tables written once. `Known` marks the inner pair that sample() already holds (delta inner
+    // lobes have no evaluate(), and the reference reuses the sampled value for that term as well).
+    enum NmKnown { NM_NONE, NM_I_O, NM_RI_O, NM_I_RO };
+    template<typename R>
+    void nm_combine(const Lobe<R>& L, V3<R> i, V3<R> o, int co, R ea, R eb, NmKnown known, V3<R> f_known, R pdf_known, V3<R>* value, R* pdf)
+    {
+        const NormalMap<R>& N = L.nm;
+        const int ci = N.facets(i);
+        *value = V3<R>{};
+        *pdf = R(0);
+        if(ci == 0 && co == 0) return;
+        const R lambda = ci == 0 ? R(0) : ci == 2 ? R(1) : N.hits_p(i);
+        auto inner = [&](NmKnown which, V3<R> a, V3<R> b, V3<R>& f, R& q) {
+            if(which == known)
+            {
+                f = f_known;
+                q = pdf_known;
+                return;
+            }
+            V3<R> la = N.to_p(a), lb = N.to_p(b);
+            f = lobe_evaluate(L, la, lb, ea, eb);
+            q = lobe_pdf(L, la, lb, ea, eb);
+        };
+        V3<R> sum{};
+        R q_sum = R(0);
+        if(co != 0)  // o leaves the mapped facet directly: routes P and TP
+        {
+            const R open = co == 2 ? N.open_p(o) : R(1);
+            const R o_dot_p = dot(o, N.p);
+            V3<R> f;
+            R q;
+            if(ci != 0)
+            {
+                inner(NM_I_O, i, o, f, q);
+                sum = sum + f * (lambda * o_dot_p * open);
+                q_sum += lambda * q * open;
+            }
+            if(ci != 2)
+            {
+                inner(NM_RI_O, N.mirror(i), o, f, q);
+                sum = sum + f * ((R(1) - lambda) * o_dot_p * open);
+                q_sum += (R(1) - lambda) * q;  // no visibility term on this route in pdf (:640-648, :690-693)
+            }
+        }
+        if(co != 2 && ci != 0)  // route PT
+        {
+            V3<R> ro = N.mirror(o);
+            const R ro_dot_p = dot(ro, N.p);
+            const R hidden = R(1) - N.open_p(ro);
+            V3<R> f;
+            R q;
+            inner(NM_I_RO, i, ro, f, q);
+            sum = sum + f * (lambda * hidden * ro_dot_p * (co == 0 ? N.open_t(o) : R(1)));
+            q_sum += lambda * q * hidden;
+        }
+        *value = sum / o.y;
+        *pdf = q_sum;
+    }
+    template<typename R> V3<R> mapped_evaluate(const Lobe<R>& L, V3<R> i, V3<R> o, R ea, R eb)
+    {
+        if(!L.nm.on) return lobe_evaluate(L, i, o, ea, eb);
+        V3<R> f;
+        R q;
+        nm_combine(L, i, o, L.nm.facets(o), ea, eb, NM_NONE, V3<R>{}, R(0), &f, &q);
+        return f;
+    }
+    template<typename R> R mapped_pdf(const Lobe<R>& L, V3<R> i, V3<R> o, R ea, R eb)
+    {
+        if(!L.nm.on) return lobe_pdf(L, i, o, ea, eb);
+        V3<R> f;
+        R q;
+        nm_combine(L, i, o, L.nm.facets(o), ea, eb, NM_NONE, V3<R>{}, R(0), &f, &q);
+        return q;
+    }
+    template<typename R> bool mapped_sample(const Lobe<R>& L, V3<R> i, R ea, R eb, R u1x, R u1y, R u2x, R u2y, V3<R>* o, V3<R>* value, R* pdf_o)
+    {
+        if(!L.nm.on) return lobe_sample(L, i, ea, eb, u1x, u1y, u2x, u2y, o, value, pdf_o);
+        const NormalMap<R>& N = L.nm;
+        const int ci = N.facets(i);
+        // first encounter: the tangent facet when i cannot see p, by the projected areas when it sees both (:232)
+        const bool via_t = ci == 0 || (ci == 1 && !(u2x < N.hits_p(i)));
+        const V3<R> start = via_t ? N.mirror(i) : i;
+        V3<R> local_m, f_m;
+        R pdf_m;
+        if(!lobe_sample(L, N.to_p(start), ea, eb, u1x, u1y, u2x, u2y, &local_m, &f_m, &pdf_m)) return false;
+        V3<R> m = N.from_p(local_m);
+        if(m.y <= R(0)) return false;
+        const int cm = dot(m, N.t) > R(0) ? 1 : 2;
+        NmKnown known = via_t ? NM_RI_O : NM_I_O;
+        int co = cm;
+        *o = m;
+        if(!via_t && cm == 2 && u2y > N.open_p(m))  // leaving p behind the tangent facet: mirrored once more (:306-372, :551-603)
+        {
+            *o = N.mirror(m);
+            co = dot(*o, N.p) > R(0) ? 1 : 0;
+            known = NM_I_RO;
+        }
+        nm_combine(L, i, *o, co, ea, eb, known, f_m, pdf_m, value, pdf_o);
+        return true;
+    }
+
     template<typename R> int sample_bxdf(const Bsdf<R>& b, R u)  // bsdf.hpp:46-55
     {
         for(int i = b.count - 1; i >= 0; --i)
@@ -1431,7 +1560,7 @@ namespace fco
         const Lobe<R>& L = b.lobes[l];
         R c = std::abs(wi_ws) * L.scale / (std::abs(wi_wg) * L.pdf);
         V3<R> lo = to_local(b, wo), li = to_local(b, wi);
-        V3<R> f = li.y >= R(0) ? lobe_evaluate(L, li, lo, ea, eb) : lobe_evaluate(L, -li, -lo, eb, ea);
+        V3<R> f = li.y >= R(0) ? mapped_evaluate(L, li, lo, ea, eb) : mapped_evaluate(L, -li, -lo, eb, ea);
         return c * f;
     }
     template<typename R> R bsdf_pdf_wi(const Bsdf<R>& b, int l, V3<R> wo, V3<R> wi, R ea, R eb)  // bsdf.hpp:131-141 + bxdf.hpp:117-127
@@ -1439,7 +1568,7 @@ namespace fco
         R wo_wg = dot(wo, b.ng), wo_ws = dot(wo, b.ns), wi_wg = dot(wi, b.ng), wi_ws = dot(wi, b.ns);
         if(wo_wg * wo_ws <= R(0) || wi_wg * wi_ws <= R(0)) return R(0);
         V3<R> lo = to_local(b, wo), li = to_local(b, wi);
-        return lo.y >= R(0) ? lobe_pdf(b.lobes[l], lo, li, ea, eb) : lobe_pdf(b.lobes[l], -lo, -li, eb, ea);
+        return lo.y >= R(0) ? mapped_pdf(b.lobes[l], lo, li, ea, eb) : mapped_pdf(b.lobes[l], -lo, -li, eb, ea);
     }
     template<typename R>
     bool bsdf_sample_wi(const Bsdf<R>& b, int l, V3<R> wo, R ea, R eb, R u1x, R u1y, R u2x, R u2y, V3<R>* wi, V3<R>* value, R* pdf)  // bsdf.hpp:74-100 + bxdf.hpp:69-97
@@ -1450,12 +1579,12 @@ namespace fco
         V3<R> lo = to_local(b, wo), li;
         if(lo.y >= R(0))
         {
-            if(!lobe_sample(L, lo, ea, eb, u1x, u1y, u2x, u2y, &li, value, pdf)) return false;
+            if(!mapped_sample(L, lo, ea, eb, u1x, u1y, u2x, u2y, &li, value, pdf)) return false;
             if(li.y <= R(0)) *value = *value * ((ea * ea) / (eb * eb));
         }
         else
         {
-            if(!lobe_sample(L, -lo, eb, ea, u1x, u1y, u2x, u2y, &li, value, pdf)) return false;
+            if(!mapped_sample(L, -lo, eb, ea, u1x, u1y, u2x, u2y, &li, value, pdf)) return false;
             li = -li;
             if(li.y >= R(0)) *value = *value * ((eb * eb) / (ea * ea));
         }

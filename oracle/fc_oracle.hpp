@@ -83,9 +83,37 @@ namespace fco
 
     enum LobeKind { LAMBERT, GGX_REFLECTION, SPECULAR_REFLECTION, GGX_GLASS, SPECULAR_GLASS, GGX_TRANSMISSION, SPECULAR_TRANSMISSION };
 
+    // normal_mapping<T> (bsdfs/normal_mapping.hpp): a microsurface of two facets, one with the mapped normal p and a
+    // vertical "tangent" facet t that closes the profile and reflects specularly. All vectors live in the
+    // shading frame (y up). off = the skip_ path (p within 0.001 of the shading normal, :745-749).
+    template<typename R>
+    struct NormalMap
+    {
+        bool on{};
+        V3<R> p{}, t{}, tangent{}, bitangent{};
+        V3<R> to_p(V3<R> w) const { return {dot(w, tangent), dot(w, p), dot(w, bitangent)}; }  // frame.hpp:22-25
+        V3<R> from_p(V3<R> w) const                                                            // frame.hpp:27-34
+        {
+            return {tangent.x * w.x + p.x * w.y + bitangent.x * w.z, tangent.y * w.x + p.y * w.y + bitangent.y * w.z,
+                    tangent.z * w.x + p.z * w.y + bitangent.z * w.z};
+        }
+        V3<R> mirror(V3<R> w) const { return w - R(2) * dot(w, t) * t; }  // reflection in the tangent facet
+        // which facets a direction sees: 0 = only the tangent facet, 1 = both, 2 = only the mapped facet (:42-43)
+        int facets(V3<R> w) const { return dot(w, p) <= R(0) ? 0 : dot(w, t) > R(0) ? 1 : 2; }
+        R sine() const { return std::sqrt(R(1) - p.y * p.y); }
+        R hits_p(V3<R> w) const  // probability that a ray along w meets the mapped facet first (:66-69)
+        {
+            R a_p = dot(w, p) / p.y, a_t = dot(w, t) * sine() / p.y;
+            return a_p / (a_p + a_t);
+        }
+        R open_p(V3<R> w) const { return w.y * p.y / dot(w, p); }             // part of facet p not hidden behind t (gp_*)
+        R open_t(V3<R> w) const { return w.y * p.y / (dot(w, t) * sine()); }  // same for the tangent facet (gt_*)
+    };
+
     template<typename R>
     struct Lobe
     {
+        NormalMap<R> nm{};
         LobeKind kind{};
         bool fresnel_dielectric{};
         V3<R> reflectance{}, transmittance{};

@@ -36,6 +36,9 @@ FILMS = [
     # image textures on material parameters (image_texture_2d_rgb / image_texture_2d_r), every material class
     ("textured", "textured_scene", dict(width=48, height=32), 4, 10),
     ("textured_len4", "textured_scene", dict(width=36, height=24), 6, 4),
+    # normal maps: normal_mapping<T> around lambertian, specular and microfacet reflection lobes
+    ("normal_mapped", "normal_mapped_scene", dict(width=48, height=32), 4, 10),
+    ("normal_mapped_len3", "normal_mapped_scene", dict(width=40, height=28), 6, 3),
 ] + [("sweep_" + c, "room", dict(width=40, height=24, tess=2, center=c), 4, 10) for c in S.CENTER_MATERIALS]
 
 # stratified mode of include/fcgpu_sampler.h (the stream is ours, the integrators consuming it are the

@@ -296,6 +296,11 @@ namespace
             }
             return std::make_shared<const_texture_2d_rgb>(vector3{c[0], c[1], c[2]});
         };
+        auto normal_map = [&](std::int32_t handle) -> std::shared_ptr<texture_2d_rgb> {
+            if(handle <= 0) return nullptr;
+            fcgpu_texture const& t{d.textures[handle - 1]};
+            return std::shared_ptr<texture_2d_rgb>{new image_texture_2d_rgb{images.at(t.image), filter_of(t), 1}};
+        };
         auto rg = [](double const* c) { return std::make_shared<const_texture_2d_rg>(vector2{c[0], c[1]}); };
         auto r = [&](double c, std::int32_t handle) -> std::shared_ptr<texture_2d_r> {
             if(handle > 0)
@@ -308,16 +313,16 @@ namespace
         switch(m.kind)
         {
         case FCGPU_MATERIAL_DIFFUSE:
-            return std::make_shared<diffuse_material>(rgb(m.color_a, m.tex_color_a), nullptr);
+            return std::make_shared<diffuse_material>(rgb(m.color_a, m.tex_color_a), normal_map(m.tex_normal));
         case FCGPU_MATERIAL_MIRROR:
-            return std::make_shared<mirror_material>(rgb(m.color_a, m.tex_color_a), rg(m.roughness));
+            return std::make_shared<mirror_material>(rgb(m.color_a, m.tex_color_a), rg(m.roughness), normal_map(m.tex_normal));
         case FCGPU_MATERIAL_GLASS:
             return std::make_shared<glass_material>(rgb(m.color_a, m.tex_color_a), rgb(m.color_b, m.tex_color_b), rg(m.roughness));
         case FCGPU_MATERIAL_PLASTIC:
             return std::make_shared<plastic_material>(rgb(m.color_a, m.tex_color_a), rgb(m.color_b, m.tex_color_b), rg(m.roughness), r(m.ior, m.tex_ior));
         case FCGPU_MATERIAL_STANDARD:
             return std::make_shared<standard_material>(rgb(m.color_a, m.tex_color_a), r(m.metalness, m.tex_metalness), r(m.roughness[0], m.tex_roughness),
-                                                       r(m.ior, m.tex_ior), nullptr);
+                                                       r(m.ior, m.tex_ior), normal_map(m.tex_normal));
         case FCGPU_MATERIAL_TRANSMISSION:
             return std::make_shared<transmission_material>(rgb(m.color_b, m.tex_color_b), rg(m.roughness));
         default:

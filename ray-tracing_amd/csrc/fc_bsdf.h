@@ -388,32 +388,194 @@ namespace fcg
         }
     };
 
-    // bsdf::evaluate, bsdf.hpp:62-72 over bxdf_adapter::evaluate, bxdf.hpp:57-67
+    // ---------------------------------------------------------------- normal_mapping<T>, bsdfs/normal_mapping.hpp
+    // The mapped normal p and a vertical "tangent" facet t (which closes the profile and reflects specularly)
+    // form a two-facet microsurface in the shading frame (y up). Light goes i -> o along at most three routes:
+    //   P  : meets facet p, scatters by the inner lobe straight to o                         f(i, o)
+    //   TP : meets facet t first, is mirrored (ri), then scatters on p to o                   f(ri, o)
+    //   PT : scatters on p towards ro, the mirror image of o; facet t turns that into o        f(i, ro)
+    // evaluate (:32-145), pdf (:629-731) and sample (:147-626) enumerate the 3 x 3 facet classes of (i, o); nm_combine
+    // is those tables written once. on = false is the skip_ path (p within 0.001 of the shading normal, :745-749).
+    template<typename R>
+    struct NormalMapRec
+    {
+        bool on = false;
+        vec3<R> p, t, tangent, bitangent;
+        FC_HD vec3<R> to_p(vec3<R> w) const { return {dot(w, tangent), dot(w, p), dot(w, bitangent)}; }  // frame.hpp:22-25
+        FC_HD vec3<R> from_p(vec3<R> w) const                                                            // frame.hpp:27-34
+        {
+            return {tangent.x * w.x + p.x * w.y + bitangent.x * w.z, tangent.y * w.x + p.y * w.y + bitangent.y * w.z,
+                    tangent.z * w.x + p.z * w.y + bitangent.z * w.z};
+        }
+        FC_HD vec3<R> mirror(vec3<R> w) const { return w - t * (R(2) * dot(w, t)); }
+        // facets a direction sees: 0 = only t, 1 = both, 2 = only p (:42-43)
+        FC_HD int facets(vec3<R> w) const { return dot(w, p) <= R(0) ? 0 : (dot(w, t) > R(0) ? 1 : 2); }
+        FC_HD R sine() const { return r_sqrt(R(1) - p.y * p.y); }
+        FC_HD R hits_p(vec3<R> w) const  // probability that a ray along w meets facet p first (:66-69)
+        {
+            R a_p = dot(w, p) / p.y, a_t = dot(w, t) * sine() / p.y;
+            return a_p / (a_p + a_t);
+        }
+        FC_HD R open_p(vec3<R> w) const { return w.y * p.y / dot(w, p); }             // gp_*: part of p not hidden behind t
+        FC_HD R open_t(vec3<R> w) const { return w.y * p.y / (dot(w, t) * sine()); }  // gt_*
+    };
+
+    // the material's decode of a normal-map texel (diffuse_material.hpp:20-27 and twins) + normal_mapping::precompute (:743-760)
+    template<typename R> FC_HD NormalMapRec<R> make_normal_map(vec3<R> texel)
+    {
+        NormalMapRec<R> N;
+        vec3<R> n{texel.x * R(2) - R(1), texel.z * R(2) - R(1), texel.y * R(2) - R(1)};  // y <-> z: blue is up
+        n = normalize(n);
+        if(n.y < R(0)) n = -n;
+        if(r_abs(n.x) < R(0.001) && r_abs(n.z) < R(0.001)) return N;
+        N.on = true;
+        N.p = n;
+        N.t = normalize(vec3<R>{-n.x, R(0), -n.z});
+        N.bitangent = normalize(cross(vec3<R>{R(1), R(0), R(0)}, n));
+        N.tangent = cross(n, N.bitangent);
+        return N;
+    }
+
+    enum NmKnown { NM_NONE = 0, NM_I_O = 1, NM_RI_O = 2, NM_I_RO = 3 };  // the inner pair sample() already holds
+
     template<int TYPE, typename R>
-    FC_HD vec3<R> bsdf_evaluate(const LobeRec<R>& L, const ShadingFrame<R>& f, vec3<R> wo, vec3<R> wi, R eta_a, R eta_b)
+    FC_HD void nm_combine(const LobeRec<R>& L, const NormalMapRec<R>& N, vec3<R> i, vec3<R> o, int co, R eta_a, R eta_b, int known,
+                          vec3<R> f_known, R pdf_known, bool want_f, bool want_pdf, vec3<R>& value, R& pdf)
+    {
+        const int ci = N.facets(i);
+        value = vec3<R>{R(0), R(0), R(0)};
+        pdf = R(0);
+        if(ci == 0 && co == 0) return;
+        const R lambda = ci == 0 ? R(0) : (ci == 2 ? R(1) : N.hits_p(i));
+        auto inner = [&](int which, vec3<R> a, vec3<R> b, vec3<R>& f, R& q) {
+            if(which == known)
+            {
+                f = f_known;
+                q = pdf_known;
+                return;
+            }
+            const vec3<R> la = N.to_p(a), lb = N.to_p(b);
+            f = want_f ? lobe_evaluate<TYPE>(L, la, lb, eta_a, eta_b) : vec3<R>{R(0), R(0), R(0)};
+            q = want_pdf ? lobe_pdf<TYPE>(L, la, lb, eta_a, eta_b) : R(0);
+        };
+        vec3<R> sum{R(0), R(0), R(0)};
+        R q_sum = R(0);
+        if(co != 0)  // o leaves facet p directly: routes P and TP
+        {
+            const R open = co == 2 ? N.open_p(o) : R(1);
+            const R o_dot_p = dot(o, N.p);
+            vec3<R> f;
+            R q;
+            if(ci != 0)
+            {
+                inner(NM_I_O, i, o, f, q);
+                sum = sum + f * (lambda * o_dot_p * open);
+                q_sum += lambda * q * open;
+            }
+            if(ci != 2)
+            {
+                inner(NM_RI_O, N.mirror(i), o, f, q);
+                sum = sum + f * ((R(1) - lambda) * o_dot_p * open);
+                q_sum += (R(1) - lambda) * q;  // no visibility term on this route in pdf (:640-648, :690-693)
+            }
+        }
+        if(co != 2 && ci != 0)  // route PT
+        {
+            const vec3<R> ro = N.mirror(o);
+            const R ro_dot_p = dot(ro, N.p);
+            const R hidden = R(1) - N.open_p(ro);
+            vec3<R> f;
+            R q;
+            inner(NM_I_RO, i, ro, f, q);
+            sum = sum + f * (lambda * hidden * ro_dot_p * (co == 0 ? N.open_t(o) : R(1)));
+            q_sum += lambda * q * hidden;
+        }
+        value = sum / o.y;
+        pdf = q_sum;
+    }
+
+    template<int TYPE, typename R>
+    FC_HD vec3<R> mapped_evaluate(const LobeRec<R>& L, const NormalMapRec<R>& N, vec3<R> i, vec3<R> o, R eta_a, R eta_b)
+    {
+        if(!N.on) return lobe_evaluate<TYPE>(L, i, o, eta_a, eta_b);
+        vec3<R> f;
+        R q;
+        nm_combine<TYPE>(L, N, i, o, N.facets(o), eta_a, eta_b, NM_NONE, vec3<R>{R(0), R(0), R(0)}, R(0), true, false, f, q);
+        return f;
+    }
+    template<int TYPE, typename R>
+    FC_HD R mapped_pdf(const LobeRec<R>& L, const NormalMapRec<R>& N, vec3<R> i, vec3<R> o, R eta_a, R eta_b)
+    {
+        if(!N.on) return lobe_pdf<TYPE>(L, i, o, eta_a, eta_b);
+        vec3<R> f;
+        R q;
+        nm_combine<TYPE>(L, N, i, o, N.facets(o), eta_a, eta_b, NM_NONE, vec3<R>{R(0), R(0), R(0)}, R(0), false, true, f, q);
+        return q;
+    }
+    template<int TYPE, typename R>
+    FC_HD bool mapped_sample(const LobeRec<R>& L, const NormalMapRec<R>& N, vec3<R> i, R eta_a, R eta_b, R u1x, R u1y, R u2x, R u2y,
+                             vec3<R>& o, vec3<R>& value, R& pdf_o)
+    {
+        if(!N.on) return lobe_sample<TYPE>(L, i, eta_a, eta_b, u1x, u1y, u2x, u2y, o, value, pdf_o);
+        const int ci = N.facets(i);
+        // first encounter: facet t when i cannot see p, by the projected areas when it sees both (:232)
+        const bool via_t = ci == 0 || (ci == 1 && !(u2x < N.hits_p(i)));
+        const vec3<R> start = via_t ? N.mirror(i) : i;
+        vec3<R> local_m, f_m;
+        R pdf_m;
+        if(!lobe_sample<TYPE>(L, N.to_p(start), eta_a, eta_b, u1x, u1y, u2x, u2y, local_m, f_m, pdf_m)) return false;
+        const vec3<R> m = N.from_p(local_m);
+        if(m.y <= R(0)) return false;
+        const int cm = dot(m, N.t) > R(0) ? 1 : 2;
+        int known = via_t ? NM_RI_O : NM_I_O;
+        int co = cm;
+        o = m;
+        if(!via_t && cm == 2 && u2y > N.open_p(m))  // leaves p behind facet t: mirrored once more (:306-372, :551-603)
+        {
+            o = N.mirror(m);
+            co = dot(o, N.p) > R(0) ? 1 : 0;
+            known = NM_I_RO;
+        }
+        nm_combine<TYPE>(L, N, i, o, co, eta_a, eta_b, known, f_m, pdf_m, true, true, value, pdf_o);
+        return true;
+    }
+
+    // bsdf::evaluate, bsdf.hpp:62-72 over bxdf_adapter::evaluate, bxdf.hpp:57-67. NM: the lobe sits inside a
+    // normal_mapping<T> (diffuse / mirror / standard materials with a normal map)
+    template<int TYPE, bool NM = false, typename R>
+    FC_HD vec3<R> bsdf_evaluate(const LobeRec<R>& L, const ShadingFrame<R>& f, vec3<R> wo, vec3<R> wi, R eta_a, R eta_b,
+                                const NormalMapRec<R>* N = nullptr)
     {
         R wo_wg = dot(wo, f.ng), wo_ws = dot(wo, f.ns), wi_wg = dot(wi, f.ng), wi_ws = dot(wi, f.ns);
         if(wo_wg * wo_ws <= R(0) || wi_wg * wi_ws <= R(0)) return vec3<R>{R(0), R(0), R(0)};
         R c = r_abs(wi_ws) * L.factor / r_abs(wi_wg);
         vec3<R> lo = f.to_local(wo), li = f.to_local(wi);
-        vec3<R> v = li.y >= R(0) ? lobe_evaluate<TYPE>(L, li, lo, eta_a, eta_b) : lobe_evaluate<TYPE>(L, -li, -lo, eta_b, eta_a);
+        vec3<R> v;
+        if constexpr(NM)
+            v = li.y >= R(0) ? mapped_evaluate<TYPE>(L, *N, li, lo, eta_a, eta_b) : mapped_evaluate<TYPE>(L, *N, -li, -lo, eta_b, eta_a);
+        else
+            v = li.y >= R(0) ? lobe_evaluate<TYPE>(L, li, lo, eta_a, eta_b) : lobe_evaluate<TYPE>(L, -li, -lo, eta_b, eta_a);
         return c * v;
     }
 
     // bsdf::pdf_wi, bsdf.hpp:131-141 over bxdf_adapter::pdf_wi, bxdf.hpp:117-127
-    template<int TYPE, typename R>
-    FC_HD R bsdf_pdf_wi(const LobeRec<R>& L, const ShadingFrame<R>& f, vec3<R> wo, vec3<R> wi, R eta_a, R eta_b)
+    template<int TYPE, bool NM = false, typename R>
+    FC_HD R bsdf_pdf_wi(const LobeRec<R>& L, const ShadingFrame<R>& f, vec3<R> wo, vec3<R> wi, R eta_a, R eta_b,
+                        const NormalMapRec<R>* N = nullptr)
     {
         R wo_wg = dot(wo, f.ng), wo_ws = dot(wo, f.ns), wi_wg = dot(wi, f.ng), wi_ws = dot(wi, f.ns);
         if(wo_wg * wo_ws <= R(0) || wi_wg * wi_ws <= R(0)) return R(0);
         vec3<R> lo = f.to_local(wo), li = f.to_local(wi);
-        return lo.y >= R(0) ? lobe_pdf<TYPE>(L, lo, li, eta_a, eta_b) : lobe_pdf<TYPE>(L, -lo, -li, eta_b, eta_a);
+        if constexpr(NM)
+            return lo.y >= R(0) ? mapped_pdf<TYPE>(L, *N, lo, li, eta_a, eta_b) : mapped_pdf<TYPE>(L, *N, -lo, -li, eta_b, eta_a);
+        else
+            return lo.y >= R(0) ? lobe_pdf<TYPE>(L, lo, li, eta_a, eta_b) : lobe_pdf<TYPE>(L, -lo, -li, eta_b, eta_a);
     }
 
     // bsdf::sample_wi, bsdf.hpp:74-100 over bxdf_adapter::sample_wi, bxdf.hpp:69-97
-    template<int TYPE, typename R>
+    template<int TYPE, bool NM = false, typename R>
     FC_HD bool bsdf_sample_wi(const LobeRec<R>& L, const ShadingFrame<R>& f, vec3<R> wo, R eta_a, R eta_b,
-                              R u1x, R u1y, R u2x, R u2y, vec3<R>& wi, vec3<R>& value, R& pdf)
+                              R u1x, R u1y, R u2x, R u2y, vec3<R>& wi, vec3<R>& value, R& pdf, const NormalMapRec<R>* N = nullptr)
     {
         R wo_wg = dot(wo, f.ng), wo_ws = dot(wo, f.ns);
         if(wo_wg * wo_ws <= R(0)) return false;
@@ -421,12 +583,22 @@ namespace fcg
         vec3<R> li;
         if(lo.y >= R(0))
         {
-            if(!lobe_sample<TYPE>(L, lo, eta_a, eta_b, u1x, u1y, u2x, u2y, li, value, pdf)) return false;
+            bool ok;
+            if constexpr(NM)
+                ok = mapped_sample<TYPE>(L, *N, lo, eta_a, eta_b, u1x, u1y, u2x, u2y, li, value, pdf);
+            else
+                ok = lobe_sample<TYPE>(L, lo, eta_a, eta_b, u1x, u1y, u2x, u2y, li, value, pdf);
+            if(!ok) return false;
             if(li.y <= R(0)) value = value * ((eta_a * eta_a) / (eta_b * eta_b));
         }
         else
         {
-            if(!lobe_sample<TYPE>(L, -lo, eta_b, eta_a, u1x, u1y, u2x, u2y, li, value, pdf)) return false;
+            bool ok;
+            if constexpr(NM)
+                ok = mapped_sample<TYPE>(L, *N, -lo, eta_b, eta_a, u1x, u1y, u2x, u2y, li, value, pdf);
+            else
+                ok = lobe_sample<TYPE>(L, -lo, eta_b, eta_a, u1x, u1y, u2x, u2y, li, value, pdf);
+            if(!ok) return false;
             li = -li;
             if(li.y >= R(0)) value = value * ((eta_b * eta_b) / (eta_a * eta_a));
         }

@@ -899,23 +899,19 @@ namespace fcg
             rec.first_lobe = first;
             rec.lobe_count = n;
             rec.kind = m.kind;
-            if(m.tex_normal != 0)
-            {
-                err = "material " + std::to_string(i) + ": normal maps (tex_normal) are not supported";
-                return FCGPU_E_INVALID;
-            }
             // which parameters each material class has (its constructor's texture arguments, src/materials/*.hpp);
             // roughness is a texture_2d_rg everywhere but in standard_material and the reference has no rg image texture
             const bool std_mat = m.kind == FCGPU_MATERIAL_STANDARD;
-            const bool allowed[5]{
+            const bool allowed[6]{
                 m.kind != FCGPU_MATERIAL_TRANSMISSION,                                                                   // TEX_COLOR_A
                 m.kind == FCGPU_MATERIAL_GLASS || m.kind == FCGPU_MATERIAL_PLASTIC || m.kind == FCGPU_MATERIAL_TRANSMISSION,  // TEX_COLOR_B
                 std_mat,                                                                                                 // TEX_ROUGHNESS
                 std_mat,                                                                                                 // TEX_METALNESS
                 std_mat || m.kind == FCGPU_MATERIAL_PLASTIC,                                                             // TEX_IOR
+                std_mat || m.kind == FCGPU_MATERIAL_DIFFUSE || m.kind == FCGPU_MATERIAL_MIRROR,                          // TEX_NORMAL (normal_mapping<T>)
             };
-            const int32_t handles[5]{m.tex_color_a, m.tex_color_b, m.tex_roughness, m.tex_metalness, m.tex_ior};
-            for(int s = 0; s < 5; ++s)
+            const int32_t handles[6]{m.tex_color_a, m.tex_color_b, m.tex_roughness, m.tex_metalness, m.tex_ior, m.tex_normal};
+            for(int s = 0; s < 6; ++s)
             {
                 if(handles[s] == 0) continue;
                 if(handles[s] < 0 || static_cast<uint32_t>(handles[s]) > d.texture_count || !allowed[s])

@@ -755,6 +755,9 @@ namespace fcg
                     const vec3<R> w10 = -w12;
                     const MaterialRec mat = S.materials[ent.material];
                     LobeRec<R> L;
+                    // normal_mapping<T> wraps the lobes of diffuse / mirror / standard materials only
+                    constexpr bool NM = TEX && (KEY == L_LAMBERT || KEY == L_GGX_REFL || KEY == L_SPEC_REFL);
+                    NormalMapRec<R> nmap;
                     if(TEX && mat.textured)
                     {
                         // material::evaluate at this hit's uv (fc_material.h); k_extend picked the lobe from the same values
@@ -767,6 +770,8 @@ namespace fcg
                         lobe_pick_table(count, scales, weights, factor, cdf);
                         const int l = static_cast<int>(hit_word_lobe(hw));
                         L = material_lobe(mat.kind, val, l, types[l], factor[l], cdf[l]);
+                        if constexpr(NM)
+                            if(mat.tex[TEX_NORMAL]) nmap = make_normal_map(tex_evaluate(S.textures[mat.tex[TEX_NORMAL] - 1], tu, tv));
                     }
                     else
                     {
@@ -794,10 +799,10 @@ namespace fcg
                             R pdf_wi;
                             if(env_sample(S, ux, uy, wi, pdf_wi, Le))
                             {
-                                vec3<R> f = bsdf_evaluate<KEY>(L, sp.f, w10, wi, eta_a, eta_b);
+                                vec3<R> f = bsdf_evaluate<KEY, NM>(L, sp.f, w10, wi, eta_a, eta_b, &nmap);
                                 if(f.x != R(0) || f.y != R(0) || f.z != R(0))
                                 {
-                                    R pdf_bsdf = bsdf_pdf_wi<KEY>(L, sp.f, w10, wi, eta_a, eta_b);
+                                    R pdf_bsdf = bsdf_pdf_wi<KEY, NM>(L, sp.f, w10, wi, eta_a, eta_b, &nmap);
                                     R pdf_l = pdf_light * pdf_wi;
                                     R weight = power_heuristic(pdf_l, pdf_bsdf);
                                     vec3<R> c = (beta * f * Le) * (weight * r_abs(dot(ng, wi)) / pdf_l);  // :68
@@ -820,12 +825,12 @@ namespace fcg
                             vec3<R> LeL = dot(nL, sp.p - pL) > R(0) ? rgb(Lt.Le) : vec3<R>{R(0), R(0), R(0)};
                             vec3<R> d1L = pL - sp.p;
                             vec3<R> w1L = normalize(d1L);
-                            vec3<R> f = bsdf_evaluate<KEY>(L, sp.f, w10, w1L, eta_a, eta_b);
+                            vec3<R> f = bsdf_evaluate<KEY, NM>(L, sp.f, w10, w1L, eta_a, eta_b, &nmap);
                             if(f.x != R(0) || f.y != R(0) || f.z != R(0))
                             {
                                 R x = r_abs(dot(nL, w1L)) / dot(d1L, d1L);
                                 R G = r_abs(dot(ng, w1L)) * x;
-                                R pdf_bsdf_pL = bsdf_pdf_wi<KEY>(L, sp.f, w10, w1L, eta_a, eta_b) * x;
+                                R pdf_bsdf_pL = bsdf_pdf_wi<KEY, NM>(L, sp.f, w10, w1L, eta_a, eta_b, &nmap) * x;
                                 R pdf_light_pL = pdf_light * Lt.inv_area;
                                 R weight = power_heuristic(pdf_light_pL, pdf_bsdf_pL);
                                 vec3<R> c = (beta * f * G * LeL) * (weight / pdf_light_pL);  // :86-91
@@ -855,7 +860,7 @@ namespace fcg
                            (double)L.alpha[0], (double)L.alpha[1], (double)L.ior, (double)L.factor, (double)eta_a, (double)eta_b, (double)u1x, (double)u1y,
                            (double)u2x, (double)u2y, (double)w10.x, (double)w10.y, (double)w10.z);
 #endif
-                    if(bsdf_sample_wi<KEY>(L, sp.f, w10, eta_a, eta_b, u1x, u1y, u2x, u2y, wn, value, pdf_w12))
+                    if(bsdf_sample_wi<KEY, NM>(L, sp.f, w10, eta_a, eta_b, u1x, u1y, u2x, u2y, wn, value, pdf_w12, &nmap))
                     {
 #ifdef FCG_DEBUG_PRINT
                         printf("   -> wn %.9g %.9g %.9g value %.6g %.6g %.6g pdf %.6g\n", (double)wn.x, (double)wn.y, (double)wn.z, (double)value.x, (double)value.y, (double)value.z, (double)pdf_w12);

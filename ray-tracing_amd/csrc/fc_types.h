@@ -127,10 +127,9 @@ namespace fcg
         int32_t lobe_count;
         int32_t kind;         // FCGPU_MATERIAL_*
         int32_t textured;     // 1 = some parameter is an image texture: lobes are built per hit (fc_material.h)
-        int32_t tex[5];       // TEX_* slots: 0 = constant, k > 0 = textures[k - 1]
-        int32_t pad;
+        int32_t tex[6];       // TEX_* slots: 0 = constant (no normal map), k > 0 = textures[k - 1]
     };
-    enum TexSlot { TEX_COLOR_A = 0, TEX_COLOR_B = 1, TEX_ROUGHNESS = 2, TEX_METALNESS = 3, TEX_IOR = 4 };
+    enum TexSlot { TEX_COLOR_A = 0, TEX_COLOR_B = 1, TEX_ROUGHNESS = 2, TEX_METALNESS = 3, TEX_IOR = 4, TEX_NORMAL = 5 };
 
     template<typename R>
     struct MatParam  // the constants of fcgpu_material, by material

@@ -517,5 +517,59 @@ def textured_scene(width=96, height=64):
     return sc
 
 
+def normal_map_image(width, height, fmt="rgb8", strength=1.0, seed=0):
+    """Tangent-space normal map of a bumpy height field, encoded as the reference's materials decode it
+    (rgb * 2 - 1, then blue becomes the shading-frame up axis: diffuse_material.hpp:23-26). A quarter of the
+    rgb32 texels are exactly flat (0.5, 0.5, 1), which takes normal_mapping's skip path."""
+    rng = np.random.default_rng(seed)
+    y, x = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    h = np.sin(2 * math.pi * 2 * x / width) * np.cos(2 * math.pi * 1.5 * y / height) + 0.35 * rng.standard_normal((height, width))
+    gx = strength * (np.roll(h, -1, 1) - np.roll(h, 1, 1))
+    gy = strength * (np.roll(h, -1, 0) - np.roll(h, 1, 0))
+    n = np.stack([-gx, -gy, np.ones_like(h)], -1)
+    n /= np.linalg.norm(n, axis=2, keepdims=True)
+    enc = n * 0.5 + 0.5
+    if fmt == "rgb32":
+        enc[0::2, 0::2] = (0.5, 0.5, 1.0)
+        return enc.astype(np.float32)
+    return np.round(255.0 * enc).astype(np.uint8)
+
+
+def normal_mapped_scene(width=96, height=64):
+    """normal_mapping<T> (bsdfs/normal_mapping.hpp) over every lobe class the reference wraps: lambertian
+    (diffuse_material), specular and microfacet reflection (mirror_material), and standard_material's three
+    lobes, with strong enough tilts that all 3 x 3 facet cases of evaluate / pdf / sample occur."""
+    sc = Scene()
+    bumps8 = sc.texture(sc.image(normal_map_image(16, 16, "rgb8", 0.9, 1), "rgb8"), "bilinear")
+    bumps32 = sc.texture(sc.image(normal_map_image(12, 8, "rgb32", 1.4, 2), "rgb32"), "box")
+    waves = sc.texture(sc.image(normal_map_image(24, 12, "rgb8", 0.5, 3), "rgb8"), "bilinear")
+    paint = sc.texture(sc.image(pattern_image(8, 8, "srgb8", 2), "srgb8"), "bilinear")
+    metal_map = sc.texture(sc.image(pattern_image(6, 6, "r8", 6), "r8"), "bilinear")
+
+    sc.entity(sc.plane((0, 0, 0), (16, 16)), sc.material(A.MATERIAL_DIFFUSE, color_a=(0.7, 0.7, 0.65), tex_normal=bumps8))
+    sc.entity(sc.plane((0, 4, -6), (16, 8), (math.radians(90), 0, 0)),
+              sc.material(A.MATERIAL_MIRROR, color_a=(0.9, 0.85, 0.8), roughness=(0.2, 0.1), tex_normal=bumps32))
+    sc.entity(sc.plane((-5.5, 2.5, 0.0), (5, 8), (math.radians(90), math.radians(70), 0)),
+              sc.material(A.MATERIAL_MIRROR, color_a=(0.9, 0.9, 0.9), roughness=(0.0, 0.0), tex_normal=waves))
+    nu, nv = 12, 8
+    th, ph = np.meshgrid(np.linspace(0, math.pi, nv + 1), np.linspace(0, 2 * math.pi, nu + 1), indexing="ij")
+    p = np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3)
+    uv = np.stack([ph / (2 * math.pi), th / math.pi], -1).reshape(-1, 2)
+    i, j = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    a = (i * (nu + 1) + j).reshape(-1)
+    b, c, d = a + (nu + 1), a + (nu + 2), a + 1
+    tris = np.stack([a, c, b, a, d, c], 1).reshape(-1)
+    sc.entity(sc.mesh(p, tris, normals=p.copy(), uvs=uv, position=(-2.2, 1.3, 0.8), rotation=(0.3, 0.5, 0.1), scale=(1.3, 1.3, 1.3)),
+              sc.material(A.MATERIAL_STANDARD, roughness=(0.3, 0.3), ior=1.45, metalness=0.5, tex_color_a=paint, tex_normal=bumps8))
+    sc.entity(sc.mesh(p, tris, uvs=uv, position=(2.4, 1.15, 1.4), scale=(1.15, 1.15, 1.15)),
+              sc.material(A.MATERIAL_STANDARD, color_a=(0.85, 0.7, 0.35), roughness=(0.0, 0.0), ior=1.5, tex_metalness=metal_map, tex_normal=waves))
+    sc.entity(sc.sphere((0.2, 0.8, 2.8), 0.8), sc.material(A.MATERIAL_DIFFUSE, tex_color_a=paint, tex_normal=bumps32))
+    qp, qi = grid_quad((-1.0, 5.0, -1.0), (2.0, 0, 0), (0, 0, 2.0), 2, 2)
+    sc.entity(sc.mesh(qp, qi), sc.diffuse((0.1, 0.1, 0.1)), emission=(1.0, 0.95, 0.9), strength=20.0)
+    sc.set_env((0.3, 0.35, 0.45))
+    sc.set_camera((0.0, 3.2, 9.5), (math.radians(12.0), math.radians(180.0), 0.0), math.radians(42.0), width, height)
+    return sc
+
+
 BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo,
-            "env_texture_scene": env_texture_scene, "textured_scene": textured_scene}
+            "env_texture_scene": env_texture_scene, "textured_scene": textured_scene, "normal_mapped_scene": normal_mapped_scene}
