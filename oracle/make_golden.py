@@ -39,6 +39,8 @@ FILMS = [
     # normal maps: normal_mapping<T> around lambertian, specular and microfacet reflection lobes
     ("normal_mapped", "normal_mapped_scene", dict(width=48, height=32), 4, 10),
     ("normal_mapped_len3", "normal_mapped_scene", dict(width=40, height=28), 6, 3),
+    # BASELINE config 4: the scene_mask stand-in (standard_material with four maps under the texture environment, thin lens)
+    ("mask", "mask_scene", dict(width=40, height=60, detail=24, texture_size=32), 4, 10),
 ] + [("sweep_" + c, "room", dict(width=40, height=24, tess=2, center=c), 4, 10) for c in S.CENTER_MATERIALS]
 
 # stratified mode of include/fcgpu_sampler.h (the stream is ours, the integrators consuming it are the
@@ -47,6 +49,7 @@ FILMS = [
 FILMS_STRATIFIED = [
     ("room_t4_strat9", "room", dict(width=64, height=36, tess=4), 9, 10, 9),
     ("zoo_strat16_epoch", "primitives_zoo", dict(width=40, height=40), 20, 10, 16),
+    ("mask_strat16", "mask_scene", dict(width=32, height=48, detail=16, texture_size=16), 16, 10, 16),
 ]
 
 

@@ -571,5 +571,60 @@ def normal_mapped_scene(width=96, height=64):
     return sc
 
 
+def mask_scene(width=600, height=900, detail=48, texture_size=64):
+    """Stand-in for scene_mask (example_scenes.hpp:316-361, BASELINE config 4): one mesh with normals and uvs under
+    standard_material{basecolor srgb8, metalness r8, roughness r8, ior 1.45, normal rgb8} (all bilinear), lit only by
+    a texture_infinity_area_light (rgb32, bilinear, 4x4 integral samples, distribution = image resolution), thin-lens
+    camera {2.367, 3.216, 6.485}, yaw 196.42 deg, fov 45 deg, lens 0.05, focus 6, 600x900 -- the reference's values.
+    The mask mesh and its maps are not in the reference repository: the mesh here is a bumpy half-ellipsoid shell with
+    eye openings, the maps are procedural."""
+    sc = Scene()
+    nu, nv = 2 * detail, detail
+    th, ph = np.meshgrid(np.linspace(0.08 * math.pi, 0.92 * math.pi, nv + 1), np.linspace(0.0, math.pi, nu + 1), indexing="ij")
+    bump = 1.0 + 0.06 * np.sin(5 * ph) * np.sin(4 * th) + 0.1 * np.exp(-((ph - math.pi / 2) ** 2 + (th - 1.75) ** 2) / 0.03)  # ridges + a nose
+    x, y, z = 1.5 * bump * np.sin(th) * np.cos(ph), 2.0 * bump * np.cos(th), 1.0 * bump * np.sin(th) * np.sin(ph)
+    p = np.stack([x, y, z], -1).reshape(-1, 3)
+    uv = np.stack([ph / math.pi, (th - 0.08 * math.pi) / (0.84 * math.pi)], -1).reshape(-1, 2)
+    # vertex normals from the parametrisation
+    P = p.reshape(nv + 1, nu + 1, 3)
+    du = np.gradient(P, axis=1)
+    dv = np.gradient(P, axis=0)
+    nrm = np.cross(du, dv).reshape(-1, 3)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)
+    if np.sum(nrm * p) < 0:
+        nrm = -nrm
+    i, j = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    u_c, v_c = (j + 0.5) / nu, (i + 0.5) / nv
+    eye = ((np.abs(u_c - 0.33) < 0.07) | (np.abs(u_c - 0.67) < 0.07)) & (np.abs(v_c - 0.36) < 0.045)
+    a = (i * (nu + 1) + j)[~eye].reshape(-1)
+    b, c, d = a + (nu + 1), a + (nu + 2), a + 1
+    t0 = np.stack([a, b, c, a, c, d], 1).reshape(-1, 3)
+    # wind every triangle so that its geometric normal agrees with the vertex normals
+    g = np.cross(p[t0[:, 1]] - p[t0[:, 0]], p[t0[:, 2]] - p[t0[:, 0]])
+    flip = np.sum(g * nrm[t0[:, 0]], axis=1) < 0
+    t0[flip] = t0[flip][:, [0, 2, 1]]
+    mesh = sc.mesh(p, t0.reshape(-1), normals=nrm, uvs=uv, position=(0.67, 3.2, 0.75), rotation=(0.0, math.radians(16.42), 0.0))
+
+    n = texture_size
+    yy, xx = np.meshgrid((np.arange(n) + 0.5) / n, (np.arange(n) + 0.5) / n, indexing="ij")
+    rng = np.random.default_rng(11)
+    stripes = 0.5 + 0.5 * np.sin(14 * math.pi * xx + 3 * np.sin(4 * math.pi * yy))
+    base = np.stack([0.55 + 0.4 * stripes, 0.25 + 0.5 * (1 - stripes) * yy, 0.15 + 0.25 * xx], -1)
+    gold = (np.abs(yy - 0.5) < 0.08) | (np.hypot(xx - 0.5, yy - 0.8) < 0.12)  # gilded band and chin
+    base[gold] = (0.95, 0.75, 0.35)
+    basecolor = sc.texture(sc.image(np.round(255 * np.clip(base, 0, 1)).astype(np.uint8), "srgb8"), "bilinear")
+    metalness = sc.texture(sc.image(np.where(gold, 255, 0).astype(np.uint8), "r8"), "bilinear")
+    rough = np.clip(0.25 + 0.35 * stripes + 0.1 * rng.standard_normal((n, n)), 0.02, 1.0)
+    rough[gold] = 0.12
+    roughness = sc.texture(sc.image(np.round(255 * rough).astype(np.uint8), "r8"), "bilinear")
+    normal = sc.texture(sc.image(normal_map_image(n, n, "rgb8", 0.45, 5), "rgb8"), "bilinear")
+    sc.entity(mesh, sc.material(A.MATERIAL_STANDARD, ior=1.45, tex_color_a=basecolor, tex_metalness=metalness, tex_roughness=roughness, tex_normal=normal))
+
+    env = sc.image(sky_image(64, 32, "rgb32"), "rgb32")
+    sc.set_env_texture(env, strength=1.0, rotation=(0.0, 0.0, 0.0), filter="bilinear", integral_sample_count=4)
+    sc.set_camera((2.367, 3.216, 6.485), (0.0, math.radians(196.42), 0.0), math.radians(45.0), width, height, lens_radius=0.05, focus_distance=6.0)
+    return sc
+
+
 BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo,
-            "env_texture_scene": env_texture_scene, "textured_scene": textured_scene, "normal_mapped_scene": normal_mapped_scene}
+            "env_texture_scene": env_texture_scene, "textured_scene": textured_scene, "normal_mapped_scene": normal_mapped_scene, "mask_scene": mask_scene}
