@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 PIPELINE_BYTES_PER_RAY = 112.0  # 32 ray in + 16 hit out + 64 path-state share
 EXTEND_BYTES_PER_RAY = 48.0     # the extend kernel's own share of it (ray record in, hit record out)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 (vector)
 # Fabric traffic of k_extend per ray, from the rocprofv3 PMC passes kept under profiles/
 # (r01_pmc_v4_tcc_*.txt: TCC_EA0_RDREQ all 128-byte requests, TCC_EA0_WRREQ split 64/32 bytes; this is
 # what FETCH_SIZE doubled + WRITE_SIZE give on gfx950): (1.85e8*128 + 2.34e8*64 + 1.42e8*32) B over
@@ -170,6 +171,17 @@ def main():
                 "algorithmic_bytes_per_ray": EXTEND_BYTES_PER_RAY,
                 "stage_ms": {k: v[0] for k, v in stages.items()},
             }
+        # VALU side of the roofline. Model flops: 25 per child-box slab test (4 per wide-node step),
+        # 60 per primitive test (both counted on the device), 300 per ray for its half of a bounce's shading.
+        local_rays = max(1, int(c.closest_rays + c.shadow_rays))
+        flops_per_ray = (100.0 * int(c.reserved[3]) + 60.0 * int(c.reserved[4])) / local_rays + 300.0
+        out["valu"] = {
+            "model_flops_per_ray": flops_per_ray, "node_steps_per_ray": int(c.reserved[3]) / local_rays,
+            "primitive_tests_per_ray": int(c.reserved[4]) / local_rays,
+            "achieved": rays / elapsed * flops_per_ray / 1e12, "peak": VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+            "frac": rays / elapsed * flops_per_ray / 1e12 / (VALU_PEAK_TFLOPS * world),
+            "pmc": "k_extend: VALU busy 82 % of cycles at lane utilisation 0.56; k_shade: VALU busy 30 % (profiles/r01_pmc_v4_sq.txt)",
+        }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, A, args)
         print(json.dumps(out), flush=True)
