@@ -206,13 +206,20 @@ typedef struct fcgpu_scene_desc {
 #define FCGPU_INTEGRATOR_BSDF 0 /* forward_bsdf_integrator */
 #define FCGPU_INTEGRATOR_MIS 1  /* forward_mis_integrator  */
 
+/* Who builds the binary hierarchy that is then collapsed to the 4-wide device layout.
+ * HOST_SAH: the reference's own top-down SAH build (bvh_acceleration_structure.hpp:228-365), in its order.
+ * DEVICE_LBVH: Morton-order linear BVH built on the GPU, for very large meshes where the host recursion
+ * dominates scene upload; same hits (exact t ties aside), lower tree quality. */
+#define FCGPU_BVH_HOST_SAH 0
+#define FCGPU_BVH_DEVICE_LBVH 1
+
 typedef struct fcgpu_options {
     int32_t precision;          /* FCGPU_PRECISION_* */
     int32_t sort_materials;     /* 1 = material-sorted shade queues (default), 0 = single queue */
     double epsilon;             /* ray-origin offset (scene.hpp:182 uses 1e-6); <=0 selects the default:
                                    1e-6 in f64, 1e-4 in f32 (1e-6 is below fp32 resolution at |p|~16) */
     uint32_t max_paths_in_flight; /* 0 = default (2^25); a pass is split into batches of at most this */
-    uint32_t reserved;
+    uint32_t bvh_builder;       /* FCGPU_BVH_* */
 } fcgpu_options;
 
 typedef struct fcgpu_tile {
@@ -244,7 +251,8 @@ typedef struct fcgpu_counters {
     uint64_t kernel_launches;
     uint64_t reserved[7];       /* diagnostics: [0] medium-stack overflows, [1] worst-case traversal stack of the BVH,
                                    [2] binary BVH nodes, [3] node steps, [4] primitive tests, [5] traversal-stack
-                                   pushes spilled to global memory (deep BVHs only) */
+                                   pushes spilled to global memory (deep BVHs only), [6] microseconds the last
+                                   fcgpu_upload_scene spent flattening the scene incl. the BVH build */
 } fcgpu_counters;
 
 /* per-stage device time, measured with HIP events on the context's stream around each launch

@@ -13,6 +13,7 @@ IMAGE_FORMAT_IDS = {"r8": 0, "rgb8": 1, "srgb8": 2, "rgb32": 3}
 FILTER_BOX, FILTER_BILINEAR = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 INTEGRATOR_BSDF, INTEGRATOR_MIS = 0, 1
+BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
 
 E_INVALID, E_HIP, E_NOSCENE, E_LIMIT, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
@@ -96,7 +97,7 @@ class SceneDesc(C.Structure):
 class Options(C.Structure):
     _fields_ = [
         ("precision", C.c_int32), ("sort_materials", C.c_int32), ("epsilon", C.c_double),
-        ("max_paths_in_flight", C.c_uint32), ("reserved", C.c_uint32),
+        ("max_paths_in_flight", C.c_uint32), ("bvh_builder", C.c_uint32),
     ]
 
 

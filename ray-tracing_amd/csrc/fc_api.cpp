@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,7 @@ struct fcgpu_ctx
     fcgpu_options opt{};
     fcgpu_sampler_config sampler{fcgpu_sampler_random(0)};
     bool has_scene{};
+    uint64_t flatten_us{};  // host time of the last scene flattening incl. the BVH build (either builder)
     FlatScene flat;  // host copy (typed arrays are small; nodes/tris are kept for introspection)
     std::vector<void*> scene_allocs;
     std::vector<void*> queue_allocs;
@@ -605,6 +607,7 @@ extern "C"
         if(!c || !opt) return fail(c, FCGPU_E_INVALID, "null argument");
         if(opt->precision != FCGPU_PRECISION_F32 && opt->precision != FCGPU_PRECISION_F64) return fail(c, FCGPU_E_INVALID, "unknown precision");
         if(opt->max_paths_in_flight != 0 && opt->max_paths_in_flight < 256) return fail(c, FCGPU_E_INVALID, "max_paths_in_flight < 256");
+        if(opt->bvh_builder != FCGPU_BVH_HOST_SAH && opt->bvh_builder != FCGPU_BVH_DEVICE_LBVH) return fail(c, FCGPU_E_INVALID, "unknown bvh_builder");
         c->opt = *opt;
         return FCGPU_OK;
     }
@@ -630,7 +633,12 @@ extern "C"
         HIP_TRY(c, hipSetDevice(c->device));
         FlatScene flat;
         std::string err;
-        int rc = flatten_scene(*d, flat, err);
+        const HierarchyBuilder on_device = [c](const std::vector<float>& boxes, LbvhTree& tree, std::string& e) {
+            return lbvh_build(c->stream, boxes, tree, e);
+        };
+        const auto t_build = std::chrono::steady_clock::now();
+        int rc = flatten_scene(*d, flat, err, c->opt.bvh_builder == FCGPU_BVH_DEVICE_LBVH ? &on_device : nullptr);
+        c->flatten_us = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_build).count());
         if(rc != FCGPU_OK) return fail(c, rc, err);
 
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -791,6 +799,7 @@ extern "C"
         out->reserved[3] = st[ST_NODES];
         out->reserved[4] = st[ST_PRIMS];
         out->reserved[5] = st[ST_STACK_SPILL];
+        out->reserved[6] = c->flatten_us;
         return FCGPU_OK;
     }
 

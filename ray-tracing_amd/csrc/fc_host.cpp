@@ -319,6 +319,90 @@ namespace fcg
             }
         };
 
+        // ------------------------------------------------------------ hierarchy from the device builder
+        // Lays the device's (left, right, box) hierarchy out as the depth-first BinNode array the host builder
+        // produces (first child at index + 1), one primitive per leaf, and leaves refs in leaf order.
+        int build_on_device(const HierarchyBuilder& builder, std::vector<PrimRef>& refs, BinaryBvh& out, std::string& err)
+        {
+            const size_t n = refs.size();
+            std::vector<float> boxes(6 * n);
+            for(size_t i = 0; i < n; ++i)
+                for(int a = 0; a < 3; ++a)
+                {
+                    boxes[6 * i + a] = refs[i].box.lo[a];
+                    boxes[6 * i + 3 + a] = refs[i].box.hi[a];
+                }
+            LbvhTree tree;
+            int rc = builder(boxes, tree, err);
+            if(rc) return rc;
+            if(tree.order.size() != n || tree.left.size() != n - 1 || tree.right.size() != n - 1 || tree.node_boxes.size() != 6 * (n - 1))
+            {
+                err = "device hierarchy has the wrong size";
+                return FCGPU_E_HIP;
+            }
+            std::vector<PrimRef> sorted(n);
+            std::vector<uint8_t> seen(n, 0);
+            for(size_t k = 0; k < n; ++k)
+            {
+                if(tree.order[k] >= n || seen[tree.order[k]])
+                {
+                    err = "device hierarchy: leaf order is not a permutation";
+                    return FCGPU_E_HIP;
+                }
+                seen[tree.order[k]] = 1;
+                sorted[k] = refs[tree.order[k]];
+            }
+            refs.swap(sorted);
+            out.nodes.clear();
+            out.nodes.reserve(2 * n - 1);
+            out.order.resize(n);
+            for(size_t k = 0; k < n; ++k) out.order[k] = refs[k].index;
+            // explicit stack: (child reference, parent whose `a` is to receive this node's index or INVALID_U32)
+            std::vector<std::pair<int32_t, uint32_t>> stack;
+            stack.emplace_back(0, INVALID_U32);
+            size_t emitted_internal = 0;
+            while(!stack.empty())
+            {
+                auto [ref, parent] = stack.back();
+                stack.pop_back();
+                const uint32_t index = static_cast<uint32_t>(out.nodes.size());
+                if(parent != INVALID_U32) out.nodes[parent].a = index;
+                if(ref < 0)
+                {
+                    const uint32_t k = static_cast<uint32_t>(~ref);
+                    if(k >= n)
+                    {
+                        err = "device hierarchy: leaf out of range";
+                        return FCGPU_E_HIP;
+                    }
+                    out.nodes.push_back(BinNode{refs[k].box, k, 1, 0});
+                    continue;
+                }
+                if(static_cast<size_t>(ref) >= n - 1 || ++emitted_internal > n - 1)
+                {
+                    err = "device hierarchy: not a tree";
+                    return FCGPU_E_HIP;
+                }
+                BinNode node{};
+                for(int a = 0; a < 3; ++a)
+                {
+                    node.box.lo[a] = tree.node_boxes[6 * static_cast<size_t>(ref) + a];
+                    node.box.hi[a] = tree.node_boxes[6 * static_cast<size_t>(ref) + 3 + a];
+                }
+                node.interior = 1;
+                node.b = static_cast<uint16_t>(node.box.max_extent());
+                out.nodes.push_back(node);
+                stack.emplace_back(tree.right[ref], index);      // second child: its index lands in `a`
+                stack.emplace_back(tree.left[ref], INVALID_U32);  // first child: next in depth-first order
+            }
+            if(out.nodes.size() != 2 * n - 1)
+            {
+                err = "device hierarchy: node count mismatch";
+                return FCGPU_E_HIP;
+            }
+            return FCGPU_OK;
+        }
+
         // ------------------------------------------------------------ 4-wide collapse + quantisation
         struct WideChild
         {
@@ -855,7 +939,7 @@ namespace fcg
         }
     }  // namespace
 
-    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err)
+    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err, const HierarchyBuilder* device_builder)
     {
         out = FlatScene{};
         if(d.entity_count == 0 || d.surface_count == 0 || d.material_count == 0)
@@ -1214,6 +1298,12 @@ namespace fcg
 
         // ---- BVH: reference-order binary build, then the wide collapse
         BinaryBvh bin;
+        if(device_builder && refs.size() >= 2)
+        {
+            int rc = build_on_device(*device_builder, refs, bin, err);
+            if(rc) return rc;
+        }
+        else
         {
             BinaryBuilder bb{refs, bin};
             bin.order.reserve(refs.size());

@@ -1,6 +1,7 @@
 // fc_host.h -- host-side scene flattening: POD scene description -> device-ready arrays.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -59,6 +60,18 @@ namespace fcg
         int32_t width{}, height{};
     };
 
-    // Returns FCGPU_OK or a negative error code with a message in `err`.
-    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err);
+    // A binary hierarchy over n primitives as the device builder (fc_lbvh.hip) returns it: n - 1 internal nodes, root 0;
+    // a child >= 0 is an internal node, < 0 the leaf ~k holding primitive order[k].
+    struct LbvhTree
+    {
+        std::vector<uint32_t> order;
+        std::vector<int32_t> left, right;
+        std::vector<float> node_boxes;  // [n - 1][6] lo.xyz, hi.xyz
+    };
+    // boxes: [n][6] primitive bounds. Returns FCGPU_OK or an error code with a message in `err`.
+    using HierarchyBuilder = std::function<int(const std::vector<float>& boxes, LbvhTree& out, std::string& err)>;
+
+    // Returns FCGPU_OK or a negative error code with a message in `err`. `device_builder`: build the binary hierarchy
+    // there instead of with the host's reference-order SAH builder (scenes of fewer than 2 primitives always use the host).
+    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err, const HierarchyBuilder* device_builder = nullptr);
 }

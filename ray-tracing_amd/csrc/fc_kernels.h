@@ -4,6 +4,7 @@
 
 #include "../../include/fcgpu.h"
 #include "../../include/fcgpu_sampler.h"
+#include "fc_host.h"
 #include "fc_types.h"
 
 namespace fcg
@@ -32,6 +33,9 @@ namespace fcg
         int grid;       // persistent grid size (blocks of 256)
         int lds_pad_extend = 0, lds_pad_shadow = 0;  // extra dynamic LDS per block: caps the blocks per CU (tuning)
     };
+
+    // fc_lbvh.hip: binary hierarchy over primitive bounds ([n][6]) built on the device (Morton sort + Karras tree + bounds)
+    int lbvh_build(hipStream_t stream, const std::vector<float>& boxes, LbvhTree& out, std::string& err);
 
     template<typename R> void launch_generate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);
     template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);

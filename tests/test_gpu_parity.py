@@ -140,3 +140,55 @@ def test_converged_image_relmse():
     relmse = np.mean((img - ref) ** 2 / (ref ** 2 + 1e-4))
     print("relMSE, same streams, 256 spp:", relmse)
     assert relmse <= 2e-3
+
+
+# ------------------------------------------------------------------ the hierarchy built on the device (FCGPU_BVH_DEVICE_LBVH)
+@pytest.mark.parametrize("name", RAY_FIXTURES)
+def test_device_built_bvh_returns_the_reference_hits(name):
+    """Any valid BVH finds the same closest hit: the linear BVH built on the GPU must give the reference's
+    primitive ids and distances on the golden ray sets, like the host-built one."""
+    z, scene = load_rays(name)
+    with make_ctx(scene, "f64", bvh_builder="device") as ctx:
+        hits = ctx.trace_closest(z["rays"])
+        anyh = ctx.trace_any(z["rays"])
+        c = ctx.counters()
+    assert c.stack_overflows == 0 and c.reserved[2] == 2 * scene.primitive_total() - 1  # one primitive per binary leaf
+    ref_prim = z["bvh_prim"]
+    mismatch = hits["prim"] != ref_prim
+    assert mismatch.mean() <= 1e-4, f"prim id mismatches {mismatch.sum()} / {len(ref_prim)}"
+    ok = (~mismatch) & (ref_prim != 0xFFFFFFFF)
+    assert np.allclose(hits["t"][ok], z["bvh_t"][ok], rtol=1e-9, atol=1e-9)
+    assert (anyh != z["any_hit"]).mean() <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["room_t4", "zoo", "mask", "nested_rough"])
+def test_device_built_bvh_radiance_f64_matches_reference(name):
+    z, scene = load_film(name)
+    with make_ctx(scene, "f64", bvh_builder="device") as ctx:
+        ctx.set_sampler(int(z["seed"]), stratified=film_stratified(z))
+        ctx.render_pass(0, int(z["spp"]), A.INTEGRATOR_MIS, int(z["max_path_length"]), True)
+        rgb, n = ctx.read_film()
+        c = ctx.counters()
+    assert n == int(z["mis_count"]) and c.stack_overflows == 0
+    assert pixel_rel_err(rgb, z["mis_rgb_sum"]).max() <= 1e-9
+    assert c.closest_rays == int(z["mis_rays"][0])
+
+
+def test_device_and_host_built_bvh_agree_on_a_large_mesh():
+    """196 608 wall triangles in fp32: both hierarchies cast the same rays and render the same image up to the few
+    paths whose exact-tie hits (shared triangle edges) resolve to the neighbouring triangle."""
+    scene = S.room(width=160, height=90, tess=128)
+    out = {}
+    for builder in ("host", "device"):
+        with make_ctx(scene, "f32", bvh_builder=builder) as ctx:
+            ctx.set_sampler(5)
+            ctx.render_pass(0, 4)
+            rgb, n = ctx.read_film()
+            c = ctx.counters()
+            out[builder] = (rgb / n, c.closest_rays, c.reserved[3] / (c.closest_rays + c.shadow_rays), c.reserved[6])
+            assert c.stack_overflows == 0 and c.nan_samples == 0
+    print({k: dict(node_steps_per_ray=round(v[2], 2), flatten_ms=v[3] / 1e3) for k, v in out.items()})
+    a, b = out["host"][0], out["device"][0]
+    rel = pixel_rel_err(b, a)
+    assert np.median(rel) <= 1e-6 and (rel <= 1e-2).mean() >= 0.98
+    assert abs(int(out["host"][1]) - int(out["device"][1])) <= 1e-3 * out["host"][1]

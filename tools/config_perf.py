@@ -9,13 +9,16 @@ kw = {}
 for a in sys.argv[5:]:
     k, v = a.split("=")
     kw[k] = int(v) if v.lstrip("-").isdigit() else v
-sc = S.BUILDERS[name](width=w, height=h, **kw)
+bvh = kw.pop("bvh", "host")  # bvh=device: hierarchy built on the GPU
+t0 = time.time(); sc = S.BUILDERS[name](width=w, height=h, **kw); print(f"scene description built in {time.time() - t0:.2f} s", flush=True)
 ctx = Rn.GpuContext(0)
+ctx.set_options(bvh_builder=bvh)
 t0 = time.time(); ctx.upload_scene(sc); up = time.time() - t0
 ctx.render_pass(0, 1); ctx.sync()
 ctx.set_profiling(True); ctx.stage_times(); ctx.reset_counters(); ctx.sync()
 t0 = time.time(); ctx.render_pass(1, spp); ctx.sync(); dt = time.time() - t0
 c = ctx.counters(); st = ctx.stage_times()
 rays = c.closest_rays + c.shadow_rays
-print(f"{name} {kw} {w}x{h} {spp} spp, {sc.primitive_total()} primitives: upload {up:.2f} s, {w*h*spp/dt/1e6:.1f} Msamples/s, {rays/dt/1e9:.3f} Grays/s, "
+print(f"{name} {kw} bvh={bvh} {w}x{h} {spp} spp, {sc.primitive_total()} primitives: upload {up:.2f} s (flatten + BVH {c.reserved[6] / 1e6:.2f} s, "
+      f"{c.reserved[3] / rays:.2f} node steps/ray, stack {c.reserved[1]}), {w*h*spp/dt/1e6:.1f} Msamples/s, {rays/dt/1e9:.3f} Grays/s, "
       f"{rays/(w*h*spp):.2f} rays/sample, nan {c.nan_samples}, overflow {c.stack_overflows} | " + " ".join(f"{k} {v[0]:.1f}" for k, v in st.items()))
