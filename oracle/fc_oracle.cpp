@@ -1596,6 +1596,13 @@ namespace fco
     }
 
     // ================================================================ integrators
+    struct ExternalSampler  // fc::sampler::get / advance_dimension of a host, as plain callbacks
+    {
+        void (*get)(void* user, double* x, double* y);
+        void (*advance)(void* user, int count);
+        void* user;
+    };
+
     template<typename R>
     class Tracer
     {
@@ -1617,18 +1624,40 @@ namespace fco
             stream = fcgpu_stream_begin(&sampler, static_cast<uint32_t>(px), static_cast<uint32_t>(py), sample);
             dim = 0;
         }
+        // ... or any fc::sampler handed in by a host (run_once_from below): get() / advance_dimension() forwarded
+        const ExternalSampler* external{};
         void get(R& x, R& y)
         {
+            if(external)
+            {
+                double ex, ey;
+                external->get(external->user, &ex, &ey);
+                x = R(ex);
+                y = R(ey);
+                return;
+            }
             uint64_t bits = fcgpu_stream_bits(&sampler, stream, dim++);
             x = R(fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE);
             y = R(fcgpu_sample_y24(bits) * FCGPU_SAMPLER_SCALE);
         }
         double get_x_double()
         {
+            if(external)
+            {
+                double ex, ey;
+                external->get(external->user, &ex, &ey);
+                return ex;
+            }
             uint64_t bits = fcgpu_stream_bits(&sampler, stream, dim++);
             return fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
         }
-        void advance(int n) { dim += static_cast<uint32_t>(n); }
+        void advance(int n)
+        {
+            if(external)
+                external->advance(external->user, n);
+            else
+                dim += static_cast<uint32_t>(n);
+        }
 
         void record(V3<R> o, V3<R> d, R t_max, uint32_t kind, uint32_t prim, double t)
         {
@@ -1834,7 +1863,13 @@ namespace fco
             V3<R> plane{((R(px) + dx) / R(S.cam.width) - R(0.5)) * S.plane_w, (R(0.5) - (R(py) + dy) / R(S.cam.height)) * S.plane_h, S.focus};
             V3<R> dir = plane - lens;
             V3<R> wi = S.cam_xf.dir(dir / std::sqrt(dot(dir, dir)));
+            return trace_path(mis, max_path_length, visible_env, cam, wi);
+        }
 
+        // run_once after measurement.sample_p_and_wi (forward_mis_integrator.hpp:21-210, forward_bsdf_integrator.hpp:
+        // 23-99): the bounce loop from a camera point along wi, beta0 = 1
+        V3<R> trace_path(bool mis, int max_path_length, bool visible_env, const Point<R>& cam, V3<R> wi)
+        {
             V3<R> Li{};
             V3<R> beta{R(1), R(1), R(1)};
             helper_reset();
@@ -2065,6 +2100,30 @@ namespace fco
         return 0;
     }
 
+    // One integrator::run_once (integrator.hpp:13-19) after the measurement sample: the host owns camera, film and
+    // sampler (its fc::measurement / fc::sampler), this runs the bounce loop. rays[0..2] += closest, any, occluded.
+    template<typename R>
+    void run_once_from(void* handle, int integrator, int max_path_length, int visible_inf, const double* origin, const double* normal,
+                       const double* wi, const ExternalSampler* sampler, double* Li_out, uint64_t* rays)
+    {
+        const Scene<R>& S = *static_cast<Handle<R>*>(handle)->scene;
+        Tracer<R> tr{S};
+        tr.external = sampler;
+        Point<R> cam;
+        cam.position = V3<R>{R(origin[0]), R(origin[1]), R(origin[2])};
+        cam.normal = V3<R>{R(normal[0]), R(normal[1]), R(normal[2])};
+        V3<R> Li = tr.trace_path(integrator == FCGPU_INTEGRATOR_MIS, max_path_length, visible_inf != 0, cam, V3<R>{R(wi[0]), R(wi[1]), R(wi[2])});
+        Li_out[0] = static_cast<double>(Li.x);
+        Li_out[1] = static_cast<double>(Li.y);
+        Li_out[2] = static_cast<double>(Li.z);
+        if(rays)
+        {
+            rays[0] += tr.closest_rays;
+            rays[1] += tr.any_rays;
+            rays[2] += tr.any_occluded;
+        }
+    }
+
     template<typename R> int trace_closest(void* handle, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits, int brute)
     {
         const Scene<R>& S = *static_cast<Handle<R>*>(handle)->scene;
@@ -2152,6 +2211,11 @@ namespace fco
                                    int threads, double* rgb, uint64_t* cnt, fco::Stats* st, fco::RayRecord* log, uint64_t cap, uint64_t* nlog)       \
     {                                                                                                                                             \
         return fco::render<R>(h, integ, mpl, vis, seed, sb, sc, x0, y0, w, hh, threads, rgb, cnt, st, log, cap, nlog);                             \
+    }                                                                                                                                             \
+    extern "C" void PREFIX##_run_once_from(void* h, int integ, int mpl, int vis, const double* origin, const double* normal, const double* wi,     \
+                                           const fco::ExternalSampler* sampler, double* Li, uint64_t* rays)                                      \
+    {                                                                                                                                             \
+        fco::run_once_from<R>(h, integ, mpl, vis, origin, normal, wi, sampler, Li, rays);                                                        \
     }                                                                                                                                             \
     extern "C" int PREFIX##_trace_closest(void* h, uint64_t n, const fcgpu_ray* r, fcgpu_hit* o, int b) { return fco::trace_closest<R>(h, n, r, o, b); } \
     extern "C" int PREFIX##_trace_any(void* h, uint64_t n, const fcgpu_ray* r, uint8_t* o, int b) { return fco::trace_any<R>(h, n, r, o, b); }       \

@@ -106,9 +106,21 @@ class _Scene:
             pass
 
     def render(self, spp, integrator=A.INTEGRATOR_MIS, max_path_length=10, visible_env=True, seed=0, sample_begin=0,
-               tile=None, threads=1, record_rays=0, stratified=None):
+               tile=None, threads=1, record_rays=0, stratified=None, drop_in=None):
         """Returns (rgb_sum[H,W,3] f64, sample_count, Stats[, ray log]).
-        `stratified=n`: the stratified mode of fcgpu_sampler.h over n samples (default: random stream)."""
+        `stratified=n`: the stratified mode of fcgpu_sampler.h over n samples (default: random stream).
+        `drop_in=<restatement scene>` (reference backend only): the reference's driver, camera, film and sampler run
+        `gpu_forward_mis_integrator : fc::integrator` (ref_harness.cpp), whose run_once is that restatement's loop."""
+        if drop_in is not None:
+            setter = self.b._fn("_set_drop_in_integrator")
+            setter.argtypes = [C.c_void_p, C.c_void_p]
+            setter.restype = None
+            loop = C.cast(drop_in.b._fn("_run_once_from"), C.c_void_p)
+            setter(loop, drop_in.h)
+            try:
+                return self.render(spp, integrator, max_path_length, visible_env, seed, sample_begin, tile, threads, record_rays, stratified)
+            finally:
+                setter(None, None)
         f = self.b._fn("_set_stratified")
         f.argtypes = [C.c_uint32]
         f.restype = None

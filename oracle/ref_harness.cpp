@@ -407,6 +407,70 @@ namespace
     }
 }
 
+// ---------------------------------------------------------------- the drop-in integrator
+// fc::integrator whose run_once hands the bounce loop to this repository's restatement of the device algorithm, on the
+// reference's OWN measurement (camera + film) and sampler objects: single-sample debugging against the stock
+// integrators, and the proof that the integrator interface is honoured. The loop arrives as a function pointer
+// (liboracle.so: fcoracle_f64_run_once_from), so the harness links nothing of ours.
+namespace
+{
+    struct external_sampler
+    {
+        void (*get)(void* user, double* x, double* y);
+        void (*advance)(void* user, int count);
+        void* user;
+    };
+    using run_once_from_fn = void (*)(void* scene, int integrator, int max_path_length, int visible_inf, double const* origin,
+                                      double const* normal, double const* wi, external_sampler const* sampler, double* Li, std::uint64_t* rays);
+
+    class gpu_forward_mis_integrator : public fc::integrator
+    {
+    public:
+        gpu_forward_mis_integrator(run_once_from_fn loop, void* restated_scene, int kind, int max_path_length, bool visible_infinity_area_light,
+                                   shared_state* counters)
+            : loop_{loop}, scene_{restated_scene}, kind_{kind}, max_path_length_{max_path_length}, visible_{visible_infinity_area_light}, counters_{counters}
+        { }
+
+        void run_once(fc::measurement& measurement, fc::scene const&, fc::sampler& sampler, fc::allocator_wrapper& allocator) const override
+        {
+            using namespace fc;
+            measurement.add_sample_count(1);
+            auto ms{measurement.sample_p_and_wi(sampler.get(), sampler.get(), allocator)};  // as forward_mis_integrator.hpp:17
+            if(!ms) return;
+            vector3 beta{ms->Wo * (std::abs(dot(ms->p->get_normal(), ms->wi)) / (ms->pdf_p * ms->pdf_wi))};
+            external_sampler ext{
+                [](void* user, double* x, double* y) {
+                    vector2 v{static_cast<fc::sampler*>(user)->get()};
+                    *x = v.x;
+                    *y = v.y;
+                },
+                [](void* user, int count) { static_cast<fc::sampler*>(user)->advance_dimension(count); }, &sampler};
+            vector3 o{ms->p->get_position()}, n{ms->p->get_normal()};
+            double origin[3]{o.x, o.y, o.z}, normal[3]{n.x, n.y, n.z}, wi[3]{ms->wi.x, ms->wi.y, ms->wi.z}, Li[3]{};
+            std::uint64_t rays[3]{};
+            loop_(scene_, kind_, max_path_length_, visible_ ? 1 : 0, origin, normal, wi, &ext, Li, rays);
+            if(counters_ != nullptr && counters_->count)
+            {
+                counters_->closest_rays += rays[0];
+                counters_->any_rays += rays[1];
+                counters_->any_occluded += rays[2];
+            }
+            measurement.add_sample(*ms->p, beta * vector3{Li[0], Li[1], Li[2]});
+        }
+
+    private:
+        run_once_from_fn loop_{};
+        void* scene_{};
+        int kind_{};
+        int max_path_length_{};
+        bool visible_{};
+        shared_state* counters_{};
+    };
+
+    run_once_from_fn g_shim_loop{};
+    void* g_shim_scene{};
+}
+
 extern "C"
 {
     struct fcref_stats
@@ -486,6 +550,13 @@ extern "C"
         return rs;
     }
 
+    // Route the following fcref_render calls through gpu_forward_mis_integrator (loop = null: back to the stock integrators).
+    void fcref_set_drop_in_integrator(void* loop, void* restated_scene)
+    {
+        g_shim_loop = reinterpret_cast<run_once_from_fn>(loop);
+        g_shim_scene = restated_scene;
+    }
+
     void fcref_scene_destroy(void* scene) { delete static_cast<ref_scene*>(scene); }
 
     std::uint32_t fcref_primitive_count(void* scene) { return static_cast<ref_scene*>(scene)->primitive_total; }
@@ -502,7 +573,9 @@ extern "C"
     {
         auto* rs{static_cast<ref_scene*>(scene_ptr)};
         std::shared_ptr<integrator> integ{};
-        if(integrator_kind == FCGPU_INTEGRATOR_MIS)
+        if(g_shim_loop != nullptr)
+            integ.reset(new gpu_forward_mis_integrator{g_shim_loop, g_shim_scene, integrator_kind, max_path_length, visible_inf != 0, &rs->shared});
+        else if(integrator_kind == FCGPU_INTEGRATOR_MIS)
             integ.reset(new forward_mis_integrator{max_path_length, visible_inf != 0});
         else
             integ.reset(new forward_bsdf_integrator{max_path_length});
