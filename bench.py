@@ -48,12 +48,36 @@ def cpu_baseline(S, A, args):
     tw, th = args.width // 4, args.height // 4
     tile = ((args.width - tw) // 2, (args.height - th) // 2, tw, th)
     spp = args.cpu_spp
-    _, n, st = sc.render(spp, integrator=A.INTEGRATOR_MIS, max_path_length=10, seed=0, tile=tile, threads=cores)
+    rgb, n, st = sc.render(spp, integrator=A.INTEGRATOR_MIS, max_path_length=10, seed=0, tile=tile, threads=cores)
     rays = st.closest_rays + st.any_rays
-    return {
+    out = {
         "value": rays / st.seconds / 1e6, "unit": "Mrays/s", "samples_per_s": n / st.seconds, "cores": cores, "kind": kind,
         "seconds": st.seconds, "rays_per_sample": rays / n,
         "sample": f"centre crop {tw}x{th} of the {args.width}x{args.height} frame, {spp} spp, Forward MIS, max_path_length 10, same scene and sample streams",
+    }
+    return out, rgb, tile, int(st.nan_samples)
+
+
+def parity_gate(ctx, A, args, ref_rgb, tile, ref_nan, kind):
+    """The correctness gate beside the speed: the GPU renders the CPU baseline's crop with the same
+    sample indices and streams (untimed); per-pixel radiance is compared with the CPU result."""
+    import numpy as np
+
+    ctx.clear_film()
+    ctx.reset_counters()
+    ctx.render_pass(0, args.cpu_spp, A.INTEGRATOR_MIS, 10, True, tile)
+    rgb, _ = ctx.read_film()
+    c = ctx.counters()
+    x0, y0, w, h = tile
+    a, b = rgb[y0:y0 + h, x0:x0 + w], ref_rgb[y0:y0 + h, x0:x0 + w]
+    floor = 1e-3 * max(float(np.abs(b).mean()), 1e-30)
+    rel = np.abs(a - b).max(axis=2) / np.maximum(np.abs(b).max(axis=2), floor)
+    mse = float(np.mean((a - b) ** 2) / max(float(np.mean(b)) ** 2, 1e-30))
+    return {
+        "against": kind, "pixels": int(w * h), "spp": args.cpu_spp, "dtype": args.precision,
+        "median_rel_err": float(np.median(rel)), "fraction_within_1e-2": float((rel <= 1e-2).mean()),
+        "mean_ratio": float(a.mean() / b.mean()), "rel_mse": mse,
+        "nan_samples": [int(c.nan_samples), ref_nan], "stack_overflows": int(c.stack_overflows),
     }
 
 
@@ -183,7 +207,8 @@ def main():
             "pmc": "k_extend: VALU busy 82 % of cycles at lane utilisation 0.56; k_shade: VALU busy 30 % (profiles/r01_pmc_v4_sq.txt)",
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, A, args)
+            out["cpu_baseline"], ref_rgb, tile, ref_nan = cpu_baseline(S, A, args)
+            out["parity"] = parity_gate(ctx, A, args, ref_rgb, tile, ref_nan, out["cpu_baseline"]["kind"])
         print(json.dumps(out), flush=True)
 
     ctx.close()
