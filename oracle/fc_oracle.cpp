@@ -218,7 +218,8 @@ namespace fco
             V3<T> b = v01 * (T(1) - wx) + v11 * wx;
             return a * (T(1) - wy) + b * wy;
         }
-        int px = std::min(static_cast<int>(u * T(W)), W - 1), py = std::min(static_cast<int>(v * T(H)), H - 1);
+        // (negative uv would index out of bounds in the reference; clamped on both sides here and on the device)
+        int px = std::clamp(static_cast<int>(u * T(W)), 0, W - 1), py = std::clamp(static_cast<int>(v * T(H)), 0, H - 1);
         return tx(px, py);
     }
 

@@ -34,8 +34,9 @@ namespace fcg
         }
         // box, :88-97
         int px = static_cast<int>(u * R(E.width)), py = static_cast<int>(v * R(E.height));
-        px = px < E.width - 1 ? px : E.width - 1;
-        py = py < E.height - 1 ? py : E.height - 1;
+        // the reference clamps only from above (uv below 0 indexes out of bounds there); clamped on both sides here
+        px = clampi(px, 0, E.width - 1);
+        py = clampi(py, 0, E.height - 1);
         return tex_texel(E, px, py);
     }
 

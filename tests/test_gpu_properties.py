@@ -324,3 +324,24 @@ def test_textured_material_with_uniform_images_equals_its_constant_twin():
             # path whose discrete decision flips on that ulp diverges; same bounds as the fp32 parity test
             rel = np.abs(a - b).max(2) / np.maximum(np.abs(a).max(2), 1e-3 * a.mean())
             assert np.median(rel) <= 1e-4 and (rel <= 1e-2).mean() >= 0.90 and abs(a.mean() - b.mean()) <= 0.02 * a.mean()
+
+
+def test_texture_coordinates_outside_the_unit_square_are_clamped():
+    """Mesh uvs in [-0.6, 1.7]: both filters clamp to the edge texels (the reference indexes out of bounds below 0 with
+    its box filter; device and restatement clamp), checked against the restatement in fp64."""
+    from oracle import pyref
+
+    sc = S.Scene()
+    tex_box = sc.texture(sc.image(S.pattern_image(8, 8, "rgb8", 3), "rgb8"), "box")
+    tex_lin = sc.texture(sc.image(S.pattern_image(6, 5, "rgb32", 4, 0.1, 0.9), "rgb32"), "bilinear")
+    for k, (tex, x) in enumerate(((tex_box, -2.2), (tex_lin, 2.2))):
+        qp, qi = S.grid_quad((x - 2.0, 0.0, 2.0), (4.0, 0, 0), (0, 0, -4.0), 3, 3)
+        uv = (qp[:, [0, 2]] - qp[:, [0, 2]].min(0)) / 4.0 * 2.3 - 0.6
+        sc.entity(sc.mesh(qp, qi, uvs=uv), sc.material(A.MATERIAL_DIFFUSE, tex_color_a=tex))
+    sc.entity(sc.sphere((0.0, 4.0, 0.0), 0.5), sc.diffuse((0.1, 0.1, 0.1)), emission=(1, 1, 1), strength=30.0)
+    sc.set_env((0.4, 0.4, 0.4))
+    sc.set_camera((0.0, 6.0, 6.0), (np.radians(45.0), np.radians(180.0), 0.0), np.radians(50.0), 64, 40)
+    ref, n, _ = pyref.restatement("f64").scene(sc).render(4, seed=3, threads=4)
+    rgb, m, c = render(sc, precision="f64", spp=4, seed=3)
+    assert n == m and c.nan_samples == 0 and ref.mean() > 0
+    assert (np.abs(rgb - ref).max(2) / np.maximum(np.abs(ref).max(2), 1e-3 * ref.mean())).max() <= 1e-9
