@@ -640,17 +640,26 @@ namespace fcg
             // mesh_surface.hpp:276-295 + distribution_1d::sample_discrete, distribution.hpp:94-105
             const double* cdf = S.light_cdf + Lt.cdf_offset;
             double u = u_prim;  // already in [0, 1 - 2^-24]
-            uint32_t lo = 0, hi = Lt.tri_count + 1;  // upper_bound over cdf[0..tri_count]
-            while(lo < hi)
-            {
-                uint32_t mid = (lo + hi) >> 1;
-                if(cdf[mid] > u)
-                    hi = mid;
-                else
-                    lo = mid + 1;
-            }
-            uint32_t tri = lo - 1;
+            // upper_bound(cdf, u) - 1 = the last k with cdf[k] <= u. The search is a chain of dependent loads on this
+            // kernel's critical path, so first try the cell a uniform-area mesh would give: two independent loads
+            // confirm it (cdf[g] <= u < cdf[g + 1] holds for exactly that k); any other case takes the search.
+            uint32_t tri = static_cast<uint32_t>(u * static_cast<double>(Lt.tri_count));
             if(tri >= Lt.tri_count) tri = Lt.tri_count - 1;
+            const double c0 = cdf[tri], c1 = cdf[tri + 1];
+            if(!(c0 <= u && c1 > u))
+            {
+                uint32_t lo = 0, hi = Lt.tri_count + 1;  // upper_bound over cdf[0..tri_count]
+                while(lo < hi)
+                {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if(cdf[mid] > u)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                tri = lo - 1;
+                if(tri >= Lt.tri_count) tri = Lt.tri_count - 1;
+            }
             const TriRec& T = S.tris[S.prim_info[Lt.first_prim + tri].kind_index & 0x3FFFFFFFu];
             vec3<R> p0 = ldv<R>(T.v0), p1 = ldv<R>(T.v1), p2 = ldv<R>(T.v2);
             R su0 = r_sqrt(ux);  // sample_triangle_uniform, sampling.hpp:62-66
