@@ -137,6 +137,10 @@ def main():
     for w in range(args.warmup):
         ctx.render_pass(base + w * spp, spp)
     ctx.sync()
+    if dist is not None and args.warmup > 0:
+        # warm the collective too: RCCL sets its reduce channels up on first use, which belongs to warm-up
+        D.reduce_film(film, args.width * args.height * spp * args.warmup, dst=0)
+        torch.cuda.synchronize()
     ctx.clear_film()
     ctx.reset_counters()
     if not args.no_profile:

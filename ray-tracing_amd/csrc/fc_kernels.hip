@@ -382,8 +382,14 @@ namespace fcg
                             {
                                 // bsdf::sample_bxdf, bsdf.hpp:46-55, on draw `dim_lobe`.x
                                 const MaterialRec m = S.materials[S.entities[entity].material];
-                                uint64_t bits = fcgpu_stream_bits(&B.sampler, slot_stream(B, path), dim_lobe);
-                                double u = fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
+                                // the draw decides nothing for a single-lobe material (any u picks lobe 0): its two hashes
+                                // (stream key + dimension) are skipped there; the dimension stays reserved either way
+                                double u = 0.0;
+                                if(m.lobe_count > 1 || (TEX && m.textured))
+                                {
+                                    uint64_t bits = fcgpu_stream_bits(&B.sampler, slot_stream(B, path), dim_lobe);
+                                    u = fcgpu_sample_x24(bits) * FCGPU_SAMPLER_SCALE;
+                                }
                                 if(TEX && m.textured)
                                 {
                                     R tu, tv;
