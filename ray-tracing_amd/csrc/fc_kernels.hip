@@ -23,6 +23,7 @@
 #include "fc_material.h"
 #include "fc_traverse.h"
 
+
 namespace fcg
 {
     constexpr int BLOCK = 256;
@@ -435,8 +436,8 @@ namespace fcg
                         }
                         if(key != 0xFF)
                         {
-                            Q.hit_c0[slot] = h0;
-                            Q.hit_c1[slot] = h1;
+                            st_stream(&Q.hit_c0[slot], h0);
+                            st_stream(&Q.hit_c1[slot], h1);
                         }
                         Q.hit_key[slot] = static_cast<uint8_t>(key);
                         slot = INVALID_U32;
@@ -447,7 +448,7 @@ namespace fcg
                 if(fresh != INVALID_U32)
                 {
                     slot = fresh;
-                    Vec4<R> c0 = Q.ray_c0[slot], c1 = Q.ray_c1[slot];
+                    Vec4<R> c0 = ld_stream(&Q.ray_c0[slot]), c1 = ld_stream(&Q.ray_c1[slot]);
                     unpack_ids(c1, path, ms);
                     dir = vec3<R>{c0.w, c1.x, c1.y};
                     trav_begin(T, vec3<R>{c0.x, c0.y, c0.z}, dir, consts<R>::inf);
@@ -720,7 +721,7 @@ namespace fcg
             if(i < n)
             {
                 const uint32_t hi = hit_idx[i];
-                Vec4<R> h0 = Q.hit_c0[hi], h1 = Q.hit_c1[hi];
+                Vec4<R> h0 = ld_stream(&Q.hit_c0[hi]), h1 = ld_stream(&Q.hit_c1[hi]);
                 uint32_t hw, path;  // hw = hit_word(kind | index, lobe)
                 unpack_ids(h1, hw, path);
                 uint32_t ms = unpack_word(h1.y);
@@ -912,14 +913,14 @@ namespace fcg
                 block_append2(emit_ray, emit_shadow, q_ctr, q_lds, slot_r, slot_s);
                 if(emit_ray)
                 {
-                    Q.ray_c0[slot_r] = r0;
-                    Q.ray_c1[slot_r] = r1;
+                    st_stream(&Q.ray_c0[slot_r], r0);
+                    st_stream(&Q.ray_c1[slot_r], r1);
                 }
                 if(emit_shadow)
                 {
-                    Q.sh_c0[slot_s] = s0;
-                    Q.sh_c1[slot_s] = s1;
-                    Q.sh_c2[slot_s] = s2;
+                    st_stream(&Q.sh_c0[slot_s], s0);
+                    st_stream(&Q.sh_c1[slot_s], s1);
+                    st_stream(&Q.sh_c2[slot_s], s2);
                 }
             }
         }
@@ -991,7 +992,7 @@ namespace fcg
                     else
                     {
                         // unoccluded: the light-strategy term of forward_mis_integrator.hpp:84-91
-                        Vec4<R> c2 = Q.sh_c2[slot];
+                        Vec4<R> c2 = ld_stream(&Q.sh_c2[slot]);
                         Vec4<R> acc = Q.li_shadow[path];
                         acc.x += c2.x;
                         acc.y += c2.y;
@@ -1004,7 +1005,7 @@ namespace fcg
                 if(fresh != INVALID_U32)
                 {
                     slot = fresh;
-                    Vec4<R> c0 = Q.sh_c0[slot], c1 = Q.sh_c1[slot];
+                    Vec4<R> c0 = ld_stream(&Q.sh_c0[slot]), c1 = ld_stream(&Q.sh_c1[slot]);
                     path = unpack_word(c1.w);
                     trav_begin(T, vec3<R>{c0.x, c0.y, c0.z}, vec3<R>{c0.w, c1.x, c1.y}, c1.z);
                     n_cast += 1;

@@ -370,4 +370,44 @@ namespace fcg
         unsigned long long* timeline;
         uint32_t capacity;
     };
+
+#if defined(__HIPCC__)
+    // Queue records are written once and read once, gigabytes apart: streaming ("nt") accesses keep them from evicting
+    // the BVH nodes and triangle records that every wave re-reads out of L1 / L2 (measured: k_extend -8.8 %). Only for
+    // records a wave touches as whole contiguous columns (ray, hit and shadow queues): the 64-byte path state is read
+    // as four 16-byte pieces of one line per lane, and without L1 allocation each piece becomes its own L2 request
+    // (k_shade +31 % when tried), and nt stores of it lose write combining (k_generate x4). FCG_STREAM_HINTS=0 builds without.
+#ifndef FCG_STREAM_HINTS
+#define FCG_STREAM_HINTS 1
+#endif
+    typedef unsigned int stream_u32x4 __attribute__((ext_vector_type(4)));
+    template<typename T> FC_D T ld_stream(const T* p)
+    {
+        static_assert(sizeof(T) % 16 == 0, "whole 16-byte pieces");
+#if FCG_STREAM_HINTS
+        stream_u32x4 piece[sizeof(T) / 16];
+        const stream_u32x4* src = reinterpret_cast<const stream_u32x4*>(p);
+#pragma unroll
+        for(size_t i = 0; i < sizeof(T) / 16; ++i) piece[i] = __builtin_nontemporal_load(src + i);
+        T out;
+        __builtin_memcpy(&out, piece, sizeof(T));
+        return out;
+#else
+        return *p;
+#endif
+    }
+    template<typename T> FC_D void st_stream(T* p, const T& v)
+    {
+        static_assert(sizeof(T) % 16 == 0, "whole 16-byte pieces");
+#if FCG_STREAM_HINTS
+        stream_u32x4 piece[sizeof(T) / 16];
+        __builtin_memcpy(piece, &v, sizeof(T));
+        stream_u32x4* dst = reinterpret_cast<stream_u32x4*>(p);
+#pragma unroll
+        for(size_t i = 0; i < sizeof(T) / 16; ++i) __builtin_nontemporal_store(piece[i], dst + i);
+#else
+        *p = v;
+#endif
+    }
+#endif
 }
