@@ -626,5 +626,104 @@ def mask_scene(width=600, height=900, detail=48, texture_size=64):
     return sc
 
 
+def random_scene(seed=0, width=32, height=24):
+    """A seeded random assembly of everything the hot path supports (differential testing): objects of all three
+    surface kinds on a jittered grid (no overlaps, no coplanar faces), every material class with random constant or
+    image-textured parameters and normal maps, media inside the refractive objects, an emitter, a random environment
+    (none / constant / texture) and a pinhole or thin-lens camera."""
+    rng = np.random.default_rng(1000 + seed)
+    sc = Scene()
+    col = lambda lo=0.1, hi=0.95: tuple(float(x) for x in rng.uniform(lo, hi, 3))
+    fmt_rgb = lambda: ["rgb8", "srgb8", "rgb32"][int(rng.integers(3))]
+    flt = lambda: ["box", "bilinear"][int(rng.integers(2))]
+
+    def rgb_tex():
+        f = fmt_rgb()
+        return sc.texture(sc.image(pattern_image(int(rng.integers(3, 12)), int(rng.integers(3, 12)), f, int(rng.integers(1 << 30)), 0.05, 0.95), f), flt())
+
+    def scalar_tex(lo, hi):
+        if rng.random() < 0.5:
+            return sc.texture(sc.image(pattern_image(int(rng.integers(3, 10)), int(rng.integers(3, 10)), "r8", int(rng.integers(1 << 30))), "r8"), flt())
+        return sc.texture(sc.image(pattern_image(int(rng.integers(3, 10)), int(rng.integers(3, 10)), "rgb32", int(rng.integers(1 << 30)), lo, hi), "rgb32"), flt())
+
+    def normal_tex():
+        f = ["rgb8", "rgb32"][int(rng.integers(2))]
+        return sc.texture(sc.image(normal_map_image(int(rng.integers(4, 14)), int(rng.integers(4, 14)), f, float(rng.uniform(0.2, 1.5)), int(rng.integers(1 << 30))), f), flt())
+
+    def material(kinds):
+        kind = kinds[int(rng.integers(len(kinds)))]
+        tex = {}
+        rough = (0.0, 0.0) if rng.random() < 0.35 else (float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.05, 0.6)))
+        if kind != A.MATERIAL_TRANSMISSION and rng.random() < 0.5:
+            tex["tex_color_a"] = rgb_tex()
+        if kind in (A.MATERIAL_GLASS, A.MATERIAL_PLASTIC, A.MATERIAL_TRANSMISSION) and rng.random() < 0.5:
+            tex["tex_color_b"] = rgb_tex()
+        if kind in (A.MATERIAL_PLASTIC, A.MATERIAL_STANDARD) and rng.random() < 0.4:
+            tex["tex_ior"] = sc.texture(sc.image(pattern_image(4, 4, "rgb32", int(rng.integers(1 << 30)), 1.2, 1.9), "rgb32"), flt())
+        if kind == A.MATERIAL_STANDARD:
+            if rng.random() < 0.5:
+                tex["tex_metalness"] = scalar_tex(0.0, 1.0)
+            if rng.random() < 0.5:
+                tex["tex_roughness"] = scalar_tex(0.0, 0.7)
+        if kind in (A.MATERIAL_DIFFUSE, A.MATERIAL_MIRROR, A.MATERIAL_STANDARD) and rng.random() < 0.5:
+            tex["tex_normal"] = normal_tex()
+        metal = float(rng.choice([0.0, 1.0, rng.uniform(0.1, 0.9)]))
+        return kind, sc.material(kind, color_a=col(), color_b=col(0.5, 1.0), roughness=rough if kind != A.MATERIAL_STANDARD else (rough[0], rough[0]),
+                                 ior=float(rng.uniform(1.2, 1.8)), metalness=metal, **tex)
+
+    opaque = [A.MATERIAL_DIFFUSE, A.MATERIAL_MIRROR, A.MATERIAL_PLASTIC, A.MATERIAL_STANDARD]
+    everything = opaque + [A.MATERIAL_GLASS, A.MATERIAL_TRANSMISSION]
+    sc.entity(sc.plane((0, 0, 0), (18, 18)), material(opaque)[1])
+    if rng.random() < 0.7:
+        sc.entity(sc.plane((0, 4, -7), (18, 8), (math.radians(90), 0, 0)), material(opaque)[1])
+
+    nu, nv = 10, 6
+    th, ph = np.meshgrid(np.linspace(0, math.pi, nv + 1), np.linspace(0, 2 * math.pi, nu + 1), indexing="ij")
+    sp = np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3)
+    suv = np.stack([ph / (2 * math.pi), th / math.pi], -1).reshape(-1, 2)
+    i, j = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    a = (i * (nu + 1) + j).reshape(-1)
+    stris = np.stack([a, a + (nu + 2), a + (nu + 1), a, a + 1, a + (nu + 2)], 1).reshape(-1)
+    cells = [(x, z) for x in (-4.5, -1.5, 1.5, 4.5) for z in (-3.0, 0.0, 3.0)]
+    picks = rng.permutation(len(cells))[: int(rng.integers(4, 8))]
+    priority = 1
+    for c in picks:
+        cx, cz = cells[c][0] + float(rng.uniform(-0.3, 0.3)), cells[c][1] + float(rng.uniform(-0.3, 0.3))
+        size = float(rng.uniform(0.5, 1.1))
+        lift = float(rng.uniform(0.02, 0.4))
+        kind, mat = material(everything)
+        shape = int(rng.integers(3))
+        rot = tuple(float(x) for x in rng.uniform(-0.6, 0.6, 3))
+        if shape == 0:
+            surf = sc.sphere((cx, size + lift, cz), size, rot)
+        elif shape == 1:
+            bp, bi = box_outward((-size, 0.0, -size), (size, 2 * size, size))
+            surf = sc.mesh(bp, bi, position=(cx, lift, cz), rotation=(0.0, rot[1], 0.0))
+        else:
+            surf = sc.mesh(sp, stris, normals=sp.copy() if rng.random() < 0.5 else None, uvs=suv, position=(cx, size + lift, cz), rotation=rot,
+                           scale=(size, size * float(rng.uniform(0.7, 1.0)), size))
+        med = -1
+        if kind in (A.MATERIAL_GLASS, A.MATERIAL_TRANSMISSION):
+            med = sc.medium(priority, float(rng.uniform(1.2, 1.7)), col(0.2, 0.9), float(rng.uniform(0.1, 0.8)))
+            priority += 1
+        sc.entity(surf, mat, medium=med)
+    if rng.random() < 0.5:
+        sc.entity(sc.sphere((float(rng.uniform(-2, 2)), 5.5, float(rng.uniform(-1, 2))), 0.5), sc.diffuse((0.1, 0.1, 0.1)), emission=col(0.5, 1.0), strength=float(rng.uniform(8, 25)))
+    else:
+        qp, qi = grid_quad((-1.0, 5.0, -1.0), (2.0, 0, 0), (0, 0, 2.0), 2, 2)
+        sc.entity(sc.mesh(qp, qi), sc.diffuse((0.1, 0.1, 0.1)), emission=col(0.5, 1.0), strength=float(rng.uniform(8, 25)))
+    env = int(rng.integers(3))
+    if env == 1:
+        sc.set_env(col(0.1, 0.6))
+    elif env == 2:
+        f = fmt_rgb()
+        sc.set_env_texture(sc.image(sky_image(16, 8, f), f), strength=float(rng.uniform(0.5, 2.0)), rotation=tuple(float(x) for x in rng.uniform(-1, 1, 3)),
+                           filter=flt(), integral_sample_count=int(rng.integers(1, 4)))
+    lens = float(rng.uniform(0.02, 0.1)) if rng.random() < 0.4 else 0.0
+    sc.set_camera((float(rng.uniform(-1, 1)), float(rng.uniform(2.5, 4.0)), 10.0), (math.radians(float(rng.uniform(8, 16))), math.radians(180.0), 0.0),
+                  math.radians(float(rng.uniform(38, 50))), width, height, lens_radius=lens, focus_distance=9.0)
+    return sc
+
+
 BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo,
-            "env_texture_scene": env_texture_scene, "textured_scene": textured_scene, "normal_mapped_scene": normal_mapped_scene, "mask_scene": mask_scene}
+            "env_texture_scene": env_texture_scene, "textured_scene": textured_scene, "normal_mapped_scene": normal_mapped_scene, "mask_scene": mask_scene, "random_scene": random_scene}

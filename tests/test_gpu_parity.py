@@ -192,3 +192,40 @@ def test_device_and_host_built_bvh_agree_on_a_large_mesh():
     rel = pixel_rel_err(b, a)
     assert np.median(rel) <= 1e-6 and (rel <= 1e-2).mean() >= 0.98
     assert abs(int(out["host"][1]) - int(out["device"][1])) <= 1e-3 * out["host"][1]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_f64_match_the_restatement(seed):
+    """Differential test: seeded random assemblies of every supported feature (scenes.random_scene; the restatement
+    equals the real reference on them, tests/test_oracle_vs_reference.py), GPU fp64 against the restatement."""
+    scene = S.random_scene(seed, 32, 24)
+    o = pyref.restatement("f64").scene(scene)
+    with make_ctx(scene, "f64") as ctx:
+        ctx.set_sampler(seed)
+        for integ in (A.INTEGRATOR_MIS, A.INTEGRATOR_BSDF):
+            ref, n, st = o.render(3, integrator=integ, max_path_length=8, seed=seed, threads=4)
+            ctx.clear_film()
+            ctx.reset_counters()
+            ctx.render_pass(0, 3, integ, 8, True)
+            rgb, m = ctx.read_film()
+            c = ctx.counters()
+            assert m == n and c.stack_overflows == 0
+            assert pixel_rel_err(rgb, ref).max() <= 1e-9, (seed, integ)
+            assert c.closest_rays == st.closest_rays and c.nan_samples == st.nan_samples
+            assert abs(int(c.shadow_rays) - int(st.any_rays)) <= max(8, 1e-3 * st.any_rays)
+
+
+@pytest.mark.parametrize("seed", range(12, 18))
+def test_random_scenes_stratified_on_a_device_built_bvh(seed):
+    """Same differential test with the stratified stream and the hierarchy built on the GPU."""
+    scene = S.random_scene(seed, 28, 20)
+    o = pyref.restatement("f64").scene(scene)
+    ref, n, st = o.render(4, max_path_length=6, seed=seed, threads=4, stratified=4)
+    with make_ctx(scene, "f64", bvh_builder="device") as ctx:
+        ctx.set_sampler(seed, stratified=4)
+        ctx.render_pass(0, 4, A.INTEGRATOR_MIS, 6, True)
+        rgb, m = ctx.read_film()
+        c = ctx.counters()
+    assert m == n and c.stack_overflows == 0
+    assert pixel_rel_err(rgb, ref).max() <= 1e-9
+    assert c.closest_rays == st.closest_rays and c.nan_samples == st.nan_samples

@@ -60,3 +60,17 @@ def test_drop_in_integrator_behind_the_reference_interface(builder, kw):
     c, _, _ = ref.render(1, seed=11)
     d, _, _ = orc.render(1, seed=11)
     assert np.abs(c - d).max() <= 1e-9 * np.abs(c).max()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_identical(seed):
+    """Differential test on seeded random assemblies of every supported feature (scenes.random_scene)."""
+    scene = S.random_scene(seed, 32, 24)
+    ref = pyref.reference().scene(scene)
+    orc = pyref.restatement("f64").scene(scene)
+    for integ in (A.INTEGRATOR_MIS, A.INTEGRATOR_BSDF):
+        a, an, ast = ref.render(3, integrator=integ, max_path_length=8, seed=seed, threads=4)
+        b, bn, bst = orc.render(3, integrator=integ, max_path_length=8, seed=seed, threads=4)
+        assert an == bn and a.max() > 0
+        assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max()
+        assert (ast.closest_rays, ast.any_rays, ast.any_occluded, ast.nan_samples) == (bst.closest_rays, bst.any_rays, bst.any_occluded, bst.nan_samples)
