@@ -315,13 +315,14 @@ namespace fcg
         R beta[3];
         R pdf;        // pdf_w12 of the last BSDF sample (forward_mis_integrator.hpp:104)
         R Li[3];
-        uint32_t flags;  // bit0: last lobe was delta (or camera segment): emitter hits un-weighted
-        uint32_t pad0;
+        uint32_t flags;  // bit0: last lobe was delta (or camera segment): emitter hits un-weighted (in fp64 the compiler pads to 8)
         R p1[3];      // previous vertex (un-offset), for transmittance and the area-measure pdf
         R pad1;
         R w[3];       // direction of the segment that produced the current hit (w12)
         R pad2;
     };
+
+    static_assert(sizeof(PathState<float>) == 64 && sizeof(PathState<double>) == 128, "one path state = four 16-byte (32-byte) pieces");
 
     constexpr int WORK_RANGES = 8;
 
