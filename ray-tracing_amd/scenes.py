@@ -707,6 +707,18 @@ def random_scene(seed=0, width=32, height=24):
             med = sc.medium(priority, float(rng.uniform(1.2, 1.7)), col(0.2, 0.9), float(rng.uniform(0.1, 0.8)))
             priority += 1
         sc.entity(surf, mat, medium=med)
+    if seed % 2 == 1:
+        # nested and overlapping media (priority stack, integrator.hpp:22-119): a refractive sphere with a smaller one
+        # inside and a third one cutting through its boundary, priorities in random order
+        c = (float(rng.uniform(-1.0, 1.0)), 1.6, float(rng.uniform(4.0, 5.0)))
+        prios = rng.permutation(3) + priority
+        outer = sc.medium(int(prios[0]), float(rng.uniform(1.3, 1.6)), col(0.3, 0.9), float(rng.uniform(0.1, 0.5)))
+        inner = sc.medium(int(prios[1]), float(rng.uniform(1.1, 1.8)), col(0.3, 0.9), float(rng.uniform(0.1, 0.9)))
+        cut = sc.medium(int(prios[2]), float(rng.uniform(1.2, 1.7)), col(0.3, 0.9), float(rng.uniform(0.1, 0.9)))
+        smooth = (0.0, 0.0)
+        sc.entity(sc.sphere(c, 1.5), sc.glass((1, 1, 1), col(0.7, 1.0), smooth if rng.random() < 0.6 else (0.2, 0.2)), medium=outer)
+        sc.entity(sc.sphere((c[0] + 0.2, c[1] - 0.1, c[2]), 0.6), sc.glass((1, 1, 1), col(0.7, 1.0), smooth), medium=inner)
+        sc.entity(sc.sphere((c[0] - 1.3, c[1] + 0.3, c[2] + 0.4), 0.8), sc.transmission(col(0.7, 1.0), smooth if rng.random() < 0.5 else (0.15, 0.15)), medium=cut)
     if rng.random() < 0.5:
         sc.entity(sc.sphere((float(rng.uniform(-2, 2)), 5.5, float(rng.uniform(-1, 2))), 0.5), sc.diffuse((0.1, 0.1, 0.1)), emission=col(0.5, 1.0), strength=float(rng.uniform(8, 25)))
     else:
