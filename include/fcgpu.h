@@ -152,10 +152,19 @@ typedef struct fcgpu_image {
 #define FCGPU_FILTER_BOX 0        /* image_texture.hpp:88-97   */
 #define FCGPU_FILTER_BILINEAR 1   /* image_texture.hpp:99-124 (clamp addressing) */
 
-/* image_texture_2d_rgb{image, filter, .} / image_texture_2d_r{image, filter, .} as material parameters */
+/* Textures of material parameters (src/textures/): image_texture_2d_rgb{image, filter, .} / image_texture_2d_r{image,
+ * filter, .} (image_texture.hpp) or checker_texture_2d_rgb{color_a, color_b, scale} (checker_texture.hpp:6-30: a where
+ * floor(u * scale) + floor(v * scale) is even, b elsewhere; rgb parameters only) */
+#define FCGPU_TEXTURE_IMAGE 0
+#define FCGPU_TEXTURE_CHECKER 1
 typedef struct fcgpu_texture {
-    int32_t image;   /* index into images */
-    int32_t filter;
+    int32_t image;      /* IMAGE: index into images */
+    int32_t filter;     /* IMAGE: FCGPU_FILTER_* */
+    int32_t kind;       /* FCGPU_TEXTURE_* */
+    int32_t reserved;
+    double color_a[3];  /* CHECKER */
+    double color_b[3];
+    double scale;
 } fcgpu_texture;
 
 /* texture_infinity_area_light{pr_transform{{}, rotation}, image_texture_2d_rgb{image, filter,

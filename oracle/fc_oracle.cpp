@@ -1316,16 +1316,26 @@ namespace fco
     }
 
     // material::evaluate for each class (const textures; normal_mapping on its skip_ path)
+    // texture_2d_rgb::evaluate of a material parameter: image_texture_2d_rgb (image_texture.hpp:22-33) or
+    // checker_texture_2d_rgb (checker_texture.hpp:14-20)
+    template<typename R> V3<R> texture_evaluate(const Scene<R>& scene, const fcgpu_texture& t, R u, R v)
+    {
+        if(t.kind == FCGPU_TEXTURE_CHECKER)
+        {
+            int x = static_cast<int>(std::floor(u * R(t.scale))), y = static_cast<int>(std::floor(v * R(t.scale)));
+            const double* c = (x + y) % 2 == 0 ? t.color_a : t.color_b;
+            return V3<R>{R(c[0]), R(c[1]), R(c[2])};
+        }
+        return image_evaluate<R>(scene.images[static_cast<size_t>(t.image)], t.filter, u, v);
+    }
+
     // Image textures (image_texture_2d_rgb / _r) are evaluated at p.get_uv() like each evaluate() does.
     template<typename R> Bsdf<R> material_bsdf(const fcgpu_material& m_in, const Point<R>& p, const Scene<R>* scene = nullptr)
     {
         fcgpu_material m = m_in;
         if(scene && !scene->textures.empty())
         {
-            auto tex = [&](int32_t handle) {
-                const fcgpu_texture& t = scene->textures[static_cast<size_t>(handle - 1)];
-                return image_evaluate<R>(scene->images[static_cast<size_t>(t.image)], t.filter, p.u, p.v);
-            };
+            auto tex = [&](int32_t handle) { return texture_evaluate<R>(*scene, scene->textures[static_cast<size_t>(handle - 1)], p.u, p.v); };
             auto set3 = [](double* dst, V3<R> c) {
                 dst[0] = static_cast<double>(c.x);
                 dst[1] = static_cast<double>(c.y);
@@ -1342,8 +1352,7 @@ namespace fco
         NormalMap<R> nm{};
         if(scene && m.tex_normal > 0)
         {
-            const fcgpu_texture& t = scene->textures[static_cast<size_t>(m.tex_normal - 1)];
-            V3<R> c = image_evaluate<R>(scene->images[static_cast<size_t>(t.image)], t.filter, p.u, p.v);
+            V3<R> c = texture_evaluate<R>(*scene, scene->textures[static_cast<size_t>(m.tex_normal - 1)], p.u, p.v);
             V3<R> n = c * R(2) - V3<R>{R(1), R(1), R(1)};
             std::swap(n.y, n.z);
             n = normalize(n);

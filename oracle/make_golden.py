@@ -41,6 +41,11 @@ FILMS = [
     ("normal_mapped_len3", "normal_mapped_scene", dict(width=40, height=28), 6, 3),
     # BASELINE config 4: the scene_mask stand-in (standard_material with four maps under the texture environment, thin lens)
     ("mask", "mask_scene", dict(width=40, height=60, detail=24, texture_size=32), 4, 10),
+    # the two remaining example scenes (stand-in meshes): checker_texture_2d_rgb floor under the texture environment;
+    # glass / water / ice nested by medium priority, max path length 20
+    ("material_ball", "material_ball_scene", dict(width=48, height=48, detail=16), 4, 10),
+    ("material_ball_glass", "material_ball_scene", dict(width=40, height=40, detail=12, ball="glass"), 4, 10),
+    ("glass", "glass_scene", dict(width=48, height=48, detail=16), 4, 20),
 ] + [("sweep_" + c, "room", dict(width=40, height=24, tess=2, center=c), 4, 10) for c in S.CENTER_MATERIALS]
 
 # stratified mode of include/fcgpu_sampler.h (the stream is ours, the integrators consuming it are the

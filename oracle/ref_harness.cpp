@@ -55,6 +55,7 @@
 #include "lights/const_infinity_area_light.hpp"
 #include "lights/texture_infinity_area_light.hpp"
 #include "textures/image_texture.hpp"
+#include "textures/checker_texture.hpp"
 #include "materials/diffuse_material.hpp"
 #include "materials/glass_material.hpp"
 #include "materials/mirror_material.hpp"
@@ -292,6 +293,8 @@ namespace
             if(handle > 0)
             {
                 fcgpu_texture const& t{d.textures[handle - 1]};
+                if(t.kind == FCGPU_TEXTURE_CHECKER)
+                    return std::make_shared<checker_texture_2d_rgb>(v3(t.color_a), v3(t.color_b), t.scale);
                 return std::shared_ptr<texture_2d_rgb>{new image_texture_2d_rgb{images.at(t.image), filter_of(t), 1}};
             }
             return std::make_shared<const_texture_2d_rgb>(vector3{c[0], c[1], c[2]});
@@ -299,6 +302,7 @@ namespace
         auto normal_map = [&](std::int32_t handle) -> std::shared_ptr<texture_2d_rgb> {
             if(handle <= 0) return nullptr;
             fcgpu_texture const& t{d.textures[handle - 1]};
+            if(t.kind == FCGPU_TEXTURE_CHECKER) return std::make_shared<checker_texture_2d_rgb>(v3(t.color_a), v3(t.color_b), t.scale);
             return std::shared_ptr<texture_2d_rgb>{new image_texture_2d_rgb{images.at(t.image), filter_of(t), 1}};
         };
         auto rg = [](double const* c) { return std::make_shared<const_texture_2d_rg>(vector2{c[0], c[1]}); };

@@ -11,6 +11,7 @@ ENV_NONE, ENV_CONST, ENV_TEXTURE = 0, 1, 2
 IMAGE_R8, IMAGE_RGB8, IMAGE_SRGB8, IMAGE_RGB32 = 0, 1, 2, 3
 IMAGE_FORMAT_IDS = {"r8": 0, "rgb8": 1, "srgb8": 2, "rgb32": 3}
 FILTER_BOX, FILTER_BILINEAR = 0, 1
+TEXTURE_IMAGE, TEXTURE_CHECKER = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 INTEGRATOR_BSDF, INTEGRATOR_MIS = 0, 1
 BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
@@ -39,7 +40,8 @@ class Material(C.Structure):
 
 
 class Texture(C.Structure):
-    _fields_ = [("image", C.c_int32), ("filter", C.c_int32)]
+    _fields_ = [("image", C.c_int32), ("filter", C.c_int32), ("kind", C.c_int32), ("reserved", C.c_int32),
+                ("color_a", c_double3), ("color_b", c_double3), ("scale", C.c_double)]
 
 
 class Medium(C.Structure):

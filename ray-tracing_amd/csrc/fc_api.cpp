@@ -146,12 +146,28 @@ namespace
             image_ref[k].width = im.width;
             image_ref[k].height = im.height;
             image_ref[k].filter = FCGPU_FILTER_BILINEAR;
+            image_ref[k].kind = FCGPU_TEXTURE_IMAGE;
         }
         std::vector<TexRef<R>> tex_refs;
-        for(const auto& t : c->flat.textures)
+        for(const fcgpu_texture& t : c->flat.textures)
         {
-            TexRef<R> r = image_ref[t.first];
-            r.filter = t.second;
+            TexRef<R> r{};
+            r.kind = t.kind;
+            if(t.kind == FCGPU_TEXTURE_CHECKER)
+            {
+                for(int k = 0; k < 3; ++k)
+                {
+                    r.checker_a[k] = static_cast<R>(t.color_a[k]);
+                    r.checker_b[k] = static_cast<R>(t.color_b[k]);
+                }
+                r.checker_scale = static_cast<R>(t.scale);
+            }
+            else
+            {
+                r = image_ref[t.image];
+                r.kind = FCGPU_TEXTURE_IMAGE;
+                r.filter = t.filter;
+            }
             tex_refs.push_back(r);
         }
         if((rc = upload(c, c->scene_allocs, tex_refs, &S.textures))) return rc;

@@ -19,6 +19,13 @@ namespace fcg
     // image_texture_2d_rgb::evaluate
     template<typename R> FC_D vec3<R> tex_evaluate(const TexRef<R>& E, R u, R v)
     {
+        if(E.kind == FCGPU_TEXTURE_CHECKER)
+        {
+            // checker_texture.hpp:14-20 (int arithmetic: a negative odd sum has remainder -1, which is "not 0" too)
+            const int x = static_cast<int>(r_floor(u * E.checker_scale)), y = static_cast<int>(r_floor(v * E.checker_scale));
+            const R* c = (x + y) % 2 == 0 ? E.checker_a : E.checker_b;
+            return vec3<R>{c[0], c[1], c[2]};
+        }
         if(E.filter == FCGPU_FILTER_BILINEAR)
         {
             // :99-124: texel centres at (i + 0.5) / resolution, clamp addressing

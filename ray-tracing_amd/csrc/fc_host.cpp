@@ -965,12 +965,21 @@ namespace fcg
         for(uint32_t i = 0; i < d.texture_count; ++i)
         {
             const fcgpu_texture& t = d.textures[i];
-            if(t.image < 0 || static_cast<uint32_t>(t.image) >= d.image_count || (t.filter != FCGPU_FILTER_BOX && t.filter != FCGPU_FILTER_BILINEAR))
+            if(t.kind == FCGPU_TEXTURE_CHECKER)
             {
-                err = "texture " + std::to_string(i) + ": image index or filter out of range";
+                if(!(t.scale == t.scale))
+                {
+                    err = "texture " + std::to_string(i) + ": checker scale is NaN";
+                    return FCGPU_E_INVALID;
+                }
+            }
+            else if(t.kind != FCGPU_TEXTURE_IMAGE || t.image < 0 || static_cast<uint32_t>(t.image) >= d.image_count ||
+                    (t.filter != FCGPU_FILTER_BOX && t.filter != FCGPU_FILTER_BILINEAR))
+            {
+                err = "texture " + std::to_string(i) + ": kind, image index or filter out of range";
                 return FCGPU_E_INVALID;
             }
-            out.textures.emplace_back(t.image, t.filter);
+            out.textures.push_back(t);
         }
         std::vector<LobeD> lobes;
         for(uint32_t i = 0; i < d.material_count; ++i)
@@ -1002,6 +1011,11 @@ namespace fcg
                 {
                     err = "material " + std::to_string(i) + ": texture slot " + std::to_string(s) +
                           (allowed[s] ? " names no texture" : " is not a texture parameter of this material class");
+                    return FCGPU_E_INVALID;
+                }
+                if(d.textures[handles[s] - 1].kind == FCGPU_TEXTURE_CHECKER && (s == TEX_ROUGHNESS || s == TEX_METALNESS || s == TEX_IOR))
+                {
+                    err = "material " + std::to_string(i) + ": the checker texture is an rgb texture (checker_texture_2d_rgb), slot " + std::to_string(s) + " takes a texture_2d_r";
                     return FCGPU_E_INVALID;
                 }
                 rec.tex[s] = handles[s];

@@ -52,7 +52,7 @@ namespace fcg
         uint32_t light_count{};   // incl. the environment light when present (scene.hpp:66-70)
         int32_t env_kind{};
         std::vector<FlatImage> images;
-        std::vector<std::pair<int32_t, int32_t>> textures;  // (image, filter)
+        std::vector<fcgpu_texture> textures;  // validated copies of the description's
         FlatEnvTexture env_texture;
         uint32_t max_stack{};     // worst-case traversal stack depth of the wide BVH
         uint32_t binary_nodes{};

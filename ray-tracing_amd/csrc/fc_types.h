@@ -144,7 +144,8 @@ namespace fcg
         const Vec4<R>* texels;  // row-major, top row first
         int32_t width, height;
         int32_t filter;         // FCGPU_FILTER_*
-        int32_t pad;
+        int32_t kind;           // FCGPU_TEXTURE_*: image (above) or checker_texture_2d_rgb (below)
+        R checker_a[3], checker_b[3], checker_scale;
     };
 
     constexpr int MAX_MEDIA = 15;       // 4-bit medium ids, 0 = vacuum

@@ -140,6 +140,14 @@ class Scene:
         self.textures.append(A.Texture(image=image, filter=A.FILTER_BILINEAR if filter == "bilinear" else A.FILTER_BOX))
         return len(self.textures)
 
+    def checker(self, color_a, color_b, scale):
+        """checker_texture_2d_rgb{color_a, color_b, scale} (rgb parameters only); returns a handle like texture()."""
+        t = A.Texture(kind=A.TEXTURE_CHECKER, scale=scale)
+        t.color_a[:] = color_a
+        t.color_b[:] = color_b
+        self.textures.append(t)
+        return len(self.textures)
+
     def set_env_texture(self, image, strength=1.0, rotation=(0, 0, 0), filter="bilinear", integral_sample_count=4,
                         distribution_resolution=None):
         """texture_infinity_area_light{{{}, rotation}, image_texture_2d_rgb{image, filter, integral_sample_count},
@@ -626,6 +634,84 @@ def mask_scene(width=600, height=900, detail=48, texture_size=64):
     return sc
 
 
+def uv_sphere(nu=16, nv=10):
+    """Unit sphere mesh with uvs and outward winding -> (positions, indices, uvs)."""
+    th, ph = np.meshgrid(np.linspace(0, math.pi, nv + 1), np.linspace(0, 2 * math.pi, nu + 1), indexing="ij")
+    p = np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3)
+    uv = np.stack([ph / (2 * math.pi), th / math.pi], -1).reshape(-1, 2)
+    i, j = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    a = (i * (nu + 1) + j).reshape(-1)
+    tris = np.stack([a, a + (nu + 2), a + (nu + 1), a, a + 1, a + (nu + 2)], 1).reshape(-1)
+    return p.astype(np.float32), tris.astype(np.uint32), uv.astype(np.float32)
+
+
+def cylinder(radius, y0, y1, n=24, top=True, bottom=True):
+    """Closed (or open-ended) cylinder around the y axis with outward winding -> (positions, indices)."""
+    ang = np.linspace(0, 2 * math.pi, n, endpoint=False)
+    ring = np.stack([radius * np.cos(ang), np.zeros(n), radius * np.sin(ang)], -1)
+    lo, hi = ring + (0, y0, 0), ring + (0, y1, 0)
+    pos = [lo, hi, np.array([[0, y0, 0]]), np.array([[0, y1, 0]])]
+    k = np.arange(n)
+    kn = (k + 1) % n
+    side = np.stack([k, n + k, n + kn, k, n + kn, kn], 1).reshape(-1)
+    idx = [side]
+    if bottom:
+        idx.append(np.stack([np.full(n, 2 * n), k, kn], 1).reshape(-1))
+    if top:
+        idx.append(np.stack([np.full(n, 2 * n + 1), n + kn, n + k], 1).reshape(-1))
+    return np.concatenate(pos).astype(np.float32), np.concatenate(idx).astype(np.uint32)
+
+
+def material_ball_scene(width=512, height=512, ball="diffuse", detail=24):
+    """Stand-in for scene_material_ball (example_scenes.hpp:28-99): a ball on a dark stand over a checker_texture_2d_rgb
+    floor {0.8, 0.6, scale 10} under the texture environment; camera, materials and light are the reference's values.
+    `ball` selects among the materials the reference keeps in comments: diffuse (active), glass (+ medium), mirror,
+    plastic. The ball_1 / ball_2 meshes are not in the reference repository: a uv sphere and a cylinder here."""
+    sc = Scene()
+    cp, ci = cylinder(0.9, 0.0, 0.35, detail)
+    sc.entity(sc.mesh(cp, ci), sc.diffuse((0.05, 0.05, 0.05)))
+    bp, bi, buv = uv_sphere(detail, max(6, detail // 2))
+    med = -1
+    if ball == "glass":
+        mat = sc.glass((1, 1, 1), (1, 1, 1), (0.35, 0.35))
+        med = sc.medium(1, 1.45, (0.2, 0.4, 0.8), 4.0)
+    elif ball == "mirror":
+        mat = sc.mirror((0.8, 0.8, 0.8), (0.2, 0.2))
+    elif ball == "plastic":
+        mat = sc.plastic((0.8, 0.6, 0.2), (1, 1, 1), (0.15, 0.15), 1.45)
+    else:
+        mat = sc.diffuse((0.8, 0.6, 0.2))
+    sc.entity(sc.mesh(bp, bi, normals=bp.copy(), uvs=buv, position=(0, 1.36, 0)), mat, medium=med)
+    sc.entity(sc.plane((0, 0, 0), (20, 20)), sc.material(A.MATERIAL_DIFFUSE, tex_color_a=sc.checker((0.8, 0.8, 0.8), (0.6, 0.6, 0.6), 10.0)))
+    sc.set_env_texture(sc.image(sky_image(64, 32, "rgb32"), "rgb32"), strength=1.0, filter="bilinear", integral_sample_count=4)
+    sc.set_camera((-2.15, 5.5, -3.6), (math.radians(45), math.radians(30), 0.0), math.radians(30.0), width, height)
+    return sc
+
+
+def glass_scene(width=512, height=512, detail=24):
+    """Stand-in for scene_glass (example_scenes.hpp:101-185): a glass (medium priority 2, ior 1.52) holding water
+    (priority 1, ior 1.3614, absorbing) with an ice cube (priority 2, ior 1.35) and a plastic straw, two grey planes,
+    the texture environment rotated by -15 degrees; materials, media, planes and camera are the reference's values,
+    max path length 20 as in its forward-MIS line. The meshes (glass, water, ice, tube) are stand-ins: the water
+    overlaps the glass wall on purpose, which the medium priorities resolve as the reference's nested meshes do."""
+    sc = Scene()
+    clear = lambda: sc.glass((1, 1, 1), (1, 1, 1), (0.0, 0.0))
+    gp, gi = cylinder(0.55, 0.02, 1.5, detail)
+    sc.entity(sc.mesh(gp, gi, position=(0.0, 0.0, 0.6)), clear(), medium=sc.medium(2, 1.52, (1.0, 1.0, 1.0), 1.0))
+    wp, wi = cylinder(0.5, 0.1, 1.1, detail)
+    sc.entity(sc.mesh(wp, wi, position=(0.0, 0.0, 0.6)), clear(), medium=sc.medium(1, 1.3614, (0.2, 0.6, 0.8), 4.0))
+    ip, ii = box_outward((-0.15, 0.0, -0.15), (0.15, 0.3, 0.15))
+    sc.entity(sc.mesh(ip, ii, position=(0.1, 0.7, 0.55), rotation=(0.3, 0.4, 0.2)), clear(), medium=sc.medium(2, 1.35, (0.2, 0.6, 0.8), 0.0))
+    tp, ti = cylinder(0.04, 0.0, 1.9, max(8, detail // 2))
+    sc.entity(sc.mesh(tp, ti, position=(-0.2, 0.15, 0.6), rotation=(0.0, 0.0, math.radians(-12.0))), sc.plastic((0.8, 0.1, 0.05), (1, 1, 1), (0.2, 0.2), 1.46))
+    sc.entity(sc.plane((-0.05, 0.0, 0.63), (6.0, 5.0)), sc.diffuse((0.5, 0.5, 0.5)))
+    sc.entity(sc.plane((0.25, 0.95, 2.89), (6.0, 5.0), (math.radians(-90.0), 0.0, 0.0)), sc.diffuse((0.5, 0.5, 0.5)))
+    sc.set_env_texture(sc.image(sky_image(64, 32, "rgb32"), "rgb32"), strength=1.0, rotation=(0.0, math.radians(-15.0), 0.0), filter="bilinear",
+                       integral_sample_count=4)
+    sc.set_camera((-2.79, 1.846, -5.127), (math.radians(6.119), math.radians(19.319), 0.0), math.radians(30.0), width, height)
+    return sc
+
+
 def random_scene(seed=0, width=32, height=24):
     """A seeded random assembly of everything the hot path supports (differential testing): objects of all three
     surface kinds on a jittered grid (no overlaps, no coplanar faces), every material class with random constant or
@@ -638,6 +724,8 @@ def random_scene(seed=0, width=32, height=24):
     flt = lambda: ["box", "bilinear"][int(rng.integers(2))]
 
     def rgb_tex():
+        if rng.random() < 0.25:
+            return sc.checker(col(), col(), float(rng.uniform(1.5, 12.0)))
         f = fmt_rgb()
         return sc.texture(sc.image(pattern_image(int(rng.integers(3, 12)), int(rng.integers(3, 12)), f, int(rng.integers(1 << 30)), 0.05, 0.95), f), flt())
 
@@ -738,4 +826,5 @@ def random_scene(seed=0, width=32, height=24):
 
 
 BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo,
-            "env_texture_scene": env_texture_scene, "textured_scene": textured_scene, "normal_mapped_scene": normal_mapped_scene, "mask_scene": mask_scene, "random_scene": random_scene}
+            "env_texture_scene": env_texture_scene, "textured_scene": textured_scene, "normal_mapped_scene": normal_mapped_scene, "mask_scene": mask_scene, "random_scene": random_scene,
+            "material_ball_scene": material_ball_scene, "glass_scene": glass_scene}

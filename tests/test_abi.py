@@ -28,7 +28,7 @@ def test_struct_layouts_match_header():
     # structs; the public PODs are checked here against hand-counted layouts
     assert C.sizeof(A.Surface) == 16 + 9 * 8 + 8 + 16 + 16
     assert C.sizeof(A.Material) == 8 + 10 * 8 + 6 * 4
-    assert C.sizeof(A.Texture) == 8
+    assert C.sizeof(A.Texture) == 16 + 7 * 8
     assert C.sizeof(A.Medium) == 8 + 5 * 8
     assert C.sizeof(A.Entity) == 16 + 4 * 8
     assert C.sizeof(A.Camera) == 9 * 8 + 8

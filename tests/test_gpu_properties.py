@@ -137,6 +137,16 @@ def test_error_codes():
         assert e.value.code == A.E_INVALID, (index, field)
         assert b"material" in lib.fcgpu_last_error(ctx.h)
     bad = S.textured_scene(16, 12)
+    bad.materials[2].tex_metalness = bad.checker((1, 1, 1), (0, 0, 0), 4.0)  # checker_texture_2d_rgb on a texture_2d_r parameter
+    with pytest.raises(R.FcgpuError) as e:
+        ctx.upload_scene(bad)
+    assert e.value.code == A.E_INVALID
+    bad = S.textured_scene(16, 12)
+    bad.textures[0].kind = 7
+    with pytest.raises(R.FcgpuError) as e:
+        ctx.upload_scene(bad)
+    assert e.value.code == A.E_INVALID
+    bad = S.textured_scene(16, 12)
     bad.textures[0].image = 77
     with pytest.raises(R.FcgpuError) as e:
         ctx.upload_scene(bad)
