@@ -46,6 +46,8 @@ FILMS = [
     ("material_ball", "material_ball_scene", dict(width=48, height=48, detail=16), 4, 10),
     ("material_ball_glass", "material_ball_scene", dict(width=40, height=40, detail=12, ball="glass"), 4, 10),
     ("glass", "glass_scene", dict(width=48, height=48, detail=16), 4, 20),
+    ("normals_mirror", "normals_scene", dict(width=48, height=48, map_size=16), 4, 10),
+    ("normals_diffuse", "normals_scene", dict(width=40, height=40, map_size=16, material="diffuse"), 4, 10),
 ] + [("sweep_" + c, "room", dict(width=40, height=24, tess=2, center=c), 4, 10) for c in S.CENTER_MATERIALS]
 
 # stratified mode of include/fcgpu_sampler.h (the stream is ours, the integrators consuming it are the

@@ -712,6 +712,23 @@ def glass_scene(width=512, height=512, detail=24):
     return sc
 
 
+def normals_scene(width=512, height=512, material="mirror", map_size=64):
+    """scene_normals (example_scenes.hpp:267-316): a 50 x 50 plane with a normal-mapped smooth mirror (or, as in the
+    reference's commented variant, a normal-mapped diffuse material) under a 10 x 1 plane emitter of strength 5, no
+    environment; all numbers are the reference's. Its `wallpaper-normal` image is not in the repository: a procedural
+    normal map stands in."""
+    sc = Scene()
+    nm = sc.texture(sc.image(normal_map_image(map_size, map_size, "rgb8", 0.6, 9), "rgb8"), "bilinear")
+    if material == "diffuse":
+        mat = sc.material(A.MATERIAL_DIFFUSE, color_a=(0.8, 0.8, 0.8), tex_normal=nm)
+    else:
+        mat = sc.material(A.MATERIAL_MIRROR, color_a=(0.8, 0.8, 0.8), roughness=(0.0, 0.0), tex_normal=nm)
+    sc.entity(sc.plane((0.0, 0.0, 0.0), (50.0, 50.0)), mat)
+    sc.entity(sc.plane((0.0, 1.0, 5.0), (10.0, 1.0), (math.radians(-90.0), 0.0, 0.0)), sc.diffuse((0.8, 0.8, 0.8)), emission=(1.0, 1.0, 1.0), strength=5.0)
+    sc.set_camera((0.0, 18.5, -11.0), (math.radians(60.0), 0.0, 0.0), math.radians(30.0), width, height)
+    return sc
+
+
 def random_scene(seed=0, width=32, height=24):
     """A seeded random assembly of everything the hot path supports (differential testing): objects of all three
     surface kinds on a jittered grid (no overlaps, no coplanar faces), every material class with random constant or
@@ -827,4 +844,4 @@ def random_scene(seed=0, width=32, height=24):
 
 BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo,
             "env_texture_scene": env_texture_scene, "textured_scene": textured_scene, "normal_mapped_scene": normal_mapped_scene, "mask_scene": mask_scene, "random_scene": random_scene,
-            "material_ball_scene": material_ball_scene, "glass_scene": glass_scene}
+            "material_ball_scene": material_ball_scene, "glass_scene": glass_scene, "normals_scene": normals_scene}

@@ -88,11 +88,14 @@ def test_radiance_f64_matches_reference(name):
             assert rel.max() <= 1e-9, (tag, rel.max())
             rays = z[tag + "_rays"]
             assert c.closest_rays == int(rays[0])
-            # visibility rays are cast where bsdf->evaluate() is non-zero: at grazing light directions the sign of
-            # dot(n, w) is decided by rounding (device fma contraction), so a handful of rays exist on one side
-            # only -- all of them occluded (the two counts differ by the same number), none carrying radiance
-            assert abs(int(c.shadow_rays) - int(rays[1])) <= max(8, 1e-3 * int(rays[1]))
-            assert int(c.shadow_rays) - int(rays[1]) == int(c.shadow_occluded) - int(rays[2]) or abs(int(c.shadow_occluded) - int(rays[2])) <= 8
+            # visibility rays are cast where bsdf->evaluate() is non-zero: where the light direction lies in the
+            # surface (a vertex on a plane emitter sampling that same emitter: normals_scene has 600 of them) or
+            # grazes it, the sign of dot(n, w) is decided by rounding (device fma contraction), so some rays exist
+            # on one side only -- every one of them occluded, none carrying radiance: the number of UNOCCLUDED
+            # rays, the ones that add to the film, has to agree
+            unoccluded, ref_unoccluded = int(c.shadow_rays) - int(c.shadow_occluded), int(rays[1]) - int(rays[2])
+            assert abs(unoccluded - ref_unoccluded) <= 8
+            assert abs(int(c.shadow_rays) - int(rays[1])) <= max(8, 0.05 * int(rays[1]))
             assert c.nan_samples == int(rays[3]) and c.stack_overflows == 0
 
 
