@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -92,6 +94,33 @@ namespace
     int hip_fail(fcgpu_ctx* c, hipError_t e, const char* what)
     {
         return fail(c, FCGPU_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+
+    // No C++ exception crosses the ABI (include/fcgpu.h): the entry points that allocate host memory run inside this.
+    template<typename F> int guarded(fcgpu_ctx* c, F&& body) noexcept
+    {
+        int code = FCGPU_E_INVALID;
+        const char* what = "unexpected exception";
+        try
+        {
+            return body();
+        }
+        catch(const std::bad_alloc&)
+        {
+            code = FCGPU_E_NOMEM;
+            what = "out of host memory";
+        }
+        catch(...)
+        {
+        }
+        try
+        {
+            if(c) c->err = what;
+        }
+        catch(...)
+        {
+        }
+        return code;
     }
 
 #define HIP_TRY(c, call)                                 \
@@ -287,8 +316,8 @@ namespace
         {
             c->timeline_words = static_cast<size_t>(c->grid) * 4u * 16u;
             HIP_TRY(c, hipMalloc(&p, sizeof(unsigned long long) * c->timeline_words));
-            HIP_TRY(c, hipMemset(p, 0, sizeof(unsigned long long) * c->timeline_words));
             c->queue_allocs.push_back(p);
+            HIP_TRY(c, hipMemset(p, 0, sizeof(unsigned long long) * c->timeline_words));
             Q.timeline = static_cast<unsigned long long*>(p);
             c->timeline = Q.timeline;
         }
@@ -473,41 +502,45 @@ namespace
 
     int trace_device(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits, uint8_t* occ)
     {
-        if(!c) return FCGPU_E_INVALID;
-        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
-        if(n == 0) return FCGPU_OK;
-        if(!rays || (!hits && !occ)) return fail(c, FCGPU_E_INVALID, "null buffer");
-        HIP_TRY(c, hipSetDevice(c->device));
-        return c->opt.precision == FCGPU_PRECISION_F64 ? run_trace(c, c->s64, n, rays, hits, occ) : run_trace(c, c->s32, n, rays, hits, occ);
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+            if(n == 0) return FCGPU_OK;
+            if(!rays || (!hits && !occ)) return fail(c, FCGPU_E_INVALID, "null buffer");
+            HIP_TRY(c, hipSetDevice(c->device));
+            return c->opt.precision == FCGPU_PRECISION_F64 ? run_trace(c, c->s64, n, rays, hits, occ) : run_trace(c, c->s32, n, rays, hits, occ);
+        });
     }
 
     int trace_host(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits, uint8_t* occ)
     {
-        if(!c) return FCGPU_E_INVALID;
-        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
-        if(n == 0) return FCGPU_OK;
-        if(!rays || (!hits && !occ)) return fail(c, FCGPU_E_INVALID, "null buffer");
-        HIP_TRY(c, hipSetDevice(c->device));
-        fcgpu_ray* d_rays = nullptr;
-        void* d_out = nullptr;
-        size_t out_bytes = hits ? sizeof(fcgpu_hit) * n : n;
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_rays), sizeof(fcgpu_ray) * n));
-        hipError_t e = hipMalloc(&d_out, out_bytes);
-        if(e != hipSuccess)
-        {
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+            if(n == 0) return FCGPU_OK;
+            if(!rays || (!hits && !occ)) return fail(c, FCGPU_E_INVALID, "null buffer");
+            HIP_TRY(c, hipSetDevice(c->device));
+            fcgpu_ray* d_rays = nullptr;
+            void* d_out = nullptr;
+            size_t out_bytes = hits ? sizeof(fcgpu_hit) * n : n;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_rays), sizeof(fcgpu_ray) * n));
+            hipError_t e = hipMalloc(&d_out, out_bytes);
+            if(e != hipSuccess)
+            {
+                (void)hipFree(d_rays);
+                return hip_fail(c, e, "hipMalloc");
+            }
+            int rc = FCGPU_OK;
+            e = hipMemcpyAsync(d_rays, rays, sizeof(fcgpu_ray) * n, hipMemcpyHostToDevice, c->stream);
+            if(e == hipSuccess) rc = trace_device(c, n, d_rays, hits ? static_cast<fcgpu_hit*>(d_out) : nullptr, hits ? nullptr : static_cast<uint8_t*>(d_out));
+            if(e == hipSuccess && rc == FCGPU_OK) e = hipMemcpyAsync(hits ? static_cast<void*>(hits) : static_cast<void*>(occ), d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+            if(e == hipSuccess && rc == FCGPU_OK) e = hipStreamSynchronize(c->stream);
             (void)hipFree(d_rays);
-            return hip_fail(c, e, "hipMalloc");
-        }
-        int rc = FCGPU_OK;
-        e = hipMemcpyAsync(d_rays, rays, sizeof(fcgpu_ray) * n, hipMemcpyHostToDevice, c->stream);
-        if(e == hipSuccess) rc = trace_device(c, n, d_rays, hits ? static_cast<fcgpu_hit*>(d_out) : nullptr, hits ? nullptr : static_cast<uint8_t*>(d_out));
-        if(e == hipSuccess && rc == FCGPU_OK) e = hipMemcpyAsync(hits ? static_cast<void*>(hits) : static_cast<void*>(occ), d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
-        if(e == hipSuccess && rc == FCGPU_OK) e = hipStreamSynchronize(c->stream);
-        (void)hipFree(d_rays);
-        (void)hipFree(d_out);
-        if(rc != FCGPU_OK) return rc;
-        if(e != hipSuccess) return hip_fail(c, e, "trace copy");
-        return FCGPU_OK;
+            (void)hipFree(d_out);
+            if(rc != FCGPU_OK) return rc;
+            if(e != hipSuccess) return hip_fail(c, e, "trace copy");
+            return FCGPU_OK;
+        });
     }
 }
 
@@ -620,12 +653,14 @@ extern "C"
 
     int fcgpu_set_options(fcgpu_ctx* c, const fcgpu_options* opt)
     {
-        if(!c || !opt) return fail(c, FCGPU_E_INVALID, "null argument");
-        if(opt->precision != FCGPU_PRECISION_F32 && opt->precision != FCGPU_PRECISION_F64) return fail(c, FCGPU_E_INVALID, "unknown precision");
-        if(opt->max_paths_in_flight != 0 && opt->max_paths_in_flight < 256) return fail(c, FCGPU_E_INVALID, "max_paths_in_flight < 256");
-        if(opt->bvh_builder != FCGPU_BVH_HOST_SAH && opt->bvh_builder != FCGPU_BVH_DEVICE_LBVH) return fail(c, FCGPU_E_INVALID, "unknown bvh_builder");
-        c->opt = *opt;
-        return FCGPU_OK;
+        return guarded(c, [&]() -> int {
+            if(!c || !opt) return fail(c, FCGPU_E_INVALID, "null argument");
+            if(opt->precision != FCGPU_PRECISION_F32 && opt->precision != FCGPU_PRECISION_F64) return fail(c, FCGPU_E_INVALID, "unknown precision");
+            if(opt->max_paths_in_flight != 0 && opt->max_paths_in_flight < 256) return fail(c, FCGPU_E_INVALID, "max_paths_in_flight < 256");
+            if(opt->bvh_builder != FCGPU_BVH_HOST_SAH && opt->bvh_builder != FCGPU_BVH_DEVICE_LBVH) return fail(c, FCGPU_E_INVALID, "unknown bvh_builder");
+            c->opt = *opt;
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_set_sampler(fcgpu_ctx* c, uint64_t seed)
@@ -637,94 +672,100 @@ extern "C"
 
     int fcgpu_set_sampler_stratified(fcgpu_ctx* c, uint64_t seed, uint32_t sample_count)
     {
-        if(!c) return FCGPU_E_INVALID;
-        if(sample_count == 0 || sample_count > (1u << 24)) return fail(c, FCGPU_E_INVALID, "stratified sample_count must be in [1, 2^24]");
-        c->sampler = fcgpu_sampler_stratified(seed, sample_count);
-        return FCGPU_OK;
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(sample_count == 0 || sample_count > (1u << 24)) return fail(c, FCGPU_E_INVALID, "stratified sample_count must be in [1, 2^24]");
+            c->sampler = fcgpu_sampler_stratified(seed, sample_count);
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_upload_scene(fcgpu_ctx* c, const fcgpu_scene_desc* d)
     {
-        if(!c || !d) return fail(c, FCGPU_E_INVALID, "null argument");
-        HIP_TRY(c, hipSetDevice(c->device));
-        FlatScene flat;
-        std::string err;
-        const HierarchyBuilder on_device = [c](const std::vector<float>& boxes, LbvhTree& tree, std::string& e) {
-            return lbvh_build(c->stream, boxes, tree, e);
-        };
-        const auto t_build = std::chrono::steady_clock::now();
-        int rc = flatten_scene(*d, flat, err, c->opt.bvh_builder == FCGPU_BVH_DEVICE_LBVH ? &on_device : nullptr);
-        c->flatten_us = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_build).count());
-        if(rc != FCGPU_OK) return fail(c, rc, err);
+        return guarded(c, [&]() -> int {
+            if(!c || !d) return fail(c, FCGPU_E_INVALID, "null argument");
+            HIP_TRY(c, hipSetDevice(c->device));
+            FlatScene flat;
+            std::string err;
+            const HierarchyBuilder on_device = [c](const std::vector<float>& boxes, LbvhTree& tree, std::string& e) {
+                return lbvh_build(c->stream, boxes, tree, e);
+            };
+            const auto t_build = std::chrono::steady_clock::now();
+            int rc = flatten_scene(*d, flat, err, c->opt.bvh_builder == FCGPU_BVH_DEVICE_LBVH ? &on_device : nullptr);
+            c->flatten_us = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_build).count());
+            if(rc != FCGPU_OK) return fail(c, rc, err);
 
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        free_pool(c->scene_allocs);
-        free_pool(c->queue_allocs);  // hit queues depend on the lobe types of the scene
-        c->queue_precision = -1;
-        c->has_scene = false;
-        c->flat = std::move(flat);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            free_pool(c->scene_allocs);
+            free_pool(c->queue_allocs);  // hit queues depend on the lobe types of the scene
+            c->queue_precision = -1;
+            c->has_scene = false;
+            c->flat = std::move(flat);
 
-        c->stack_spill = nullptr;
-        if(c->flat.max_stack > static_cast<uint32_t>(STACK_CAP))
-        {
-            // deep BVH: the part of the worst-case stack beyond the LDS entries lives in global memory,
-            // one column per lane of the persistent grid
-            void* p = nullptr;
-            const size_t entries = c->flat.max_stack - static_cast<uint32_t>(STACK_CAP);
-            HIP_TRY(c, hipMalloc(&p, entries * static_cast<size_t>(c->grid) * 256u * sizeof(uint32_t)));
-            c->scene_allocs.push_back(p);
-            c->stack_spill = static_cast<uint32_t*>(p);
-        }
-        SceneDev<float> a{};
-        if((rc = upload(c, c->scene_allocs, c->flat.nodes, &a.nodes))) return rc;
-        if((rc = upload(c, c->scene_allocs, c->flat.tris, &a.tris))) return rc;
-        if((rc = upload(c, c->scene_allocs, c->flat.tri_attrs, &a.tri_attrs))) return rc;
-        if((rc = upload(c, c->scene_allocs, c->flat.prim_info, &a.prim_info))) return rc;
-        if((rc = upload(c, c->scene_allocs, c->flat.entities, &a.entities))) return rc;
-        if((rc = upload(c, c->scene_allocs, c->flat.materials, &a.materials))) return rc;
-        if((rc = upload(c, c->scene_allocs, c->flat.light_cdf, &a.light_cdf))) return rc;
-        SceneDev<double> b{};
-        b.nodes = a.nodes;
-        b.tris = a.tris;
-        b.tri_attrs = a.tri_attrs;
-        b.prim_info = a.prim_info;
-        b.entities = a.entities;
-        b.materials = a.materials;
-        b.light_cdf = a.light_cdf;
-        if((rc = fill_scene(c, a, c->flat.f32))) return rc;
-        if((rc = fill_scene(c, b, c->flat.f64))) return rc;
-        c->s32 = a;
-        c->s64 = b;
+            c->stack_spill = nullptr;
+            if(c->flat.max_stack > static_cast<uint32_t>(STACK_CAP))
+            {
+                // deep BVH: the part of the worst-case stack beyond the LDS entries lives in global memory,
+                // one column per lane of the persistent grid
+                void* p = nullptr;
+                const size_t entries = c->flat.max_stack - static_cast<uint32_t>(STACK_CAP);
+                HIP_TRY(c, hipMalloc(&p, entries * static_cast<size_t>(c->grid) * 256u * sizeof(uint32_t)));
+                c->scene_allocs.push_back(p);
+                c->stack_spill = static_cast<uint32_t*>(p);
+            }
+            SceneDev<float> a{};
+            if((rc = upload(c, c->scene_allocs, c->flat.nodes, &a.nodes))) return rc;
+            if((rc = upload(c, c->scene_allocs, c->flat.tris, &a.tris))) return rc;
+            if((rc = upload(c, c->scene_allocs, c->flat.tri_attrs, &a.tri_attrs))) return rc;
+            if((rc = upload(c, c->scene_allocs, c->flat.prim_info, &a.prim_info))) return rc;
+            if((rc = upload(c, c->scene_allocs, c->flat.entities, &a.entities))) return rc;
+            if((rc = upload(c, c->scene_allocs, c->flat.materials, &a.materials))) return rc;
+            if((rc = upload(c, c->scene_allocs, c->flat.light_cdf, &a.light_cdf))) return rc;
+            SceneDev<double> b{};
+            b.nodes = a.nodes;
+            b.tris = a.tris;
+            b.tri_attrs = a.tri_attrs;
+            b.prim_info = a.prim_info;
+            b.entities = a.entities;
+            b.materials = a.materials;
+            b.light_cdf = a.light_cdf;
+            if((rc = fill_scene(c, a, c->flat.f32))) return rc;
+            if((rc = fill_scene(c, b, c->flat.f64))) return rc;
+            c->s32 = a;
+            c->s64 = b;
 
-        if(c->film) (void)hipFree(c->film);
-        c->film = nullptr;
-        c->film_elems = 3ull * static_cast<uint64_t>(c->flat.width) * static_cast<uint64_t>(c->flat.height);
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->film), sizeof(double) * c->film_elems));
-        HIP_TRY(c, hipMemset(c->film, 0, sizeof(double) * c->film_elems));
-        c->samples = 0;
-        c->has_scene = true;
-        return FCGPU_OK;
+            if(c->film) (void)hipFree(c->film);
+            c->film = nullptr;
+            c->film_elems = 3ull * static_cast<uint64_t>(c->flat.width) * static_cast<uint64_t>(c->flat.height);
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->film), sizeof(double) * c->film_elems));
+            HIP_TRY(c, hipMemset(c->film, 0, sizeof(double) * c->film_elems));
+            c->samples = 0;
+            c->has_scene = true;
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_render_pass(fcgpu_ctx* c, const fcgpu_tile* tile, uint32_t sample_begin, uint32_t sample_count, int integrator,
                           int max_path_length, int visible_infinity_area_light)
     {
-        if(!c) return FCGPU_E_INVALID;
-        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
-        fcgpu_tile full{0, 0, c->flat.width, c->flat.height};
-        if(!tile) tile = &full;
-        if(tile->w <= 0 || tile->h <= 0 || tile->x0 < 0 || tile->y0 < 0 || tile->x0 + tile->w > c->flat.width || tile->y0 + tile->h > c->flat.height)
-            return fail(c, FCGPU_E_INVALID, "tile outside the film");
-        if(integrator != FCGPU_INTEGRATOR_BSDF && integrator != FCGPU_INTEGRATOR_MIS) return fail(c, FCGPU_E_INVALID, "unknown integrator");
-        if(max_path_length < 1 || max_path_length > 1000) return fail(c, FCGPU_E_INVALID, "max_path_length out of range");
-        if(static_cast<uint64_t>(sample_begin) + sample_count > (1u << 24)) return fail(c, FCGPU_E_LIMIT, "sample index >= 2^24");
-        if(sample_count == 0) return FCGPU_OK;
-        HIP_TRY(c, hipSetDevice(c->device));
-        int rc = ensure_queues(c, static_cast<uint64_t>(tile->w) * static_cast<uint64_t>(tile->h) * sample_count);
-        if(rc) return rc;
-        if(c->opt.precision == FCGPU_PRECISION_F64)
-            return run_batches(c, c->s64, c->q64, c->q64b, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
-        return run_batches(c, c->s32, c->q32, c->q32b, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+            fcgpu_tile full{0, 0, c->flat.width, c->flat.height};
+            if(!tile) tile = &full;
+            if(tile->w <= 0 || tile->h <= 0 || tile->x0 < 0 || tile->y0 < 0 || tile->x0 + tile->w > c->flat.width || tile->y0 + tile->h > c->flat.height)
+                return fail(c, FCGPU_E_INVALID, "tile outside the film");
+            if(integrator != FCGPU_INTEGRATOR_BSDF && integrator != FCGPU_INTEGRATOR_MIS) return fail(c, FCGPU_E_INVALID, "unknown integrator");
+            if(max_path_length < 1 || max_path_length > 1000) return fail(c, FCGPU_E_INVALID, "max_path_length out of range");
+            if(static_cast<uint64_t>(sample_begin) + sample_count > (1u << 24)) return fail(c, FCGPU_E_LIMIT, "sample index >= 2^24");
+            if(sample_count == 0) return FCGPU_OK;
+            HIP_TRY(c, hipSetDevice(c->device));
+            int rc = ensure_queues(c, static_cast<uint64_t>(tile->w) * static_cast<uint64_t>(tile->h) * sample_count);
+            if(rc) return rc;
+            if(c->opt.precision == FCGPU_PRECISION_F64)
+                return run_batches(c, c->s64, c->q64, c->q64b, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
+            return run_batches(c, c->s32, c->q32, c->q32b, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
+        });
     }
 
     int fcgpu_trace_closest(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits)
@@ -750,30 +791,34 @@ extern "C"
 
     int fcgpu_clear_film(fcgpu_ctx* c)
     {
-        if(!c) return FCGPU_E_INVALID;
-        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
-        HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, hipMemsetAsync(c->film, 0, sizeof(double) * c->film_elems, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->samples = 0;
-        return FCGPU_OK;
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipMemsetAsync(c->film, 0, sizeof(double) * c->film_elems, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->samples = 0;
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_read_film(fcgpu_ctx* c, double* rgb_sum, uint64_t* sample_count)
     {
-        if(!c) return FCGPU_E_INVALID;
-        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
-        HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if(rgb_sum)
-        {
-            HIP_TRY(c, hipMemcpy(rgb_sum, c->film, sizeof(double) * c->film_elems, hipMemcpyDeviceToHost));
-            // beta0 = W*H (perspective_camera.hpp:64-68) is applied here instead of per sample
-            const double scale = static_cast<double>(c->flat.width) * static_cast<double>(c->flat.height);
-            for(uint64_t i = 0; i < c->film_elems; ++i) rgb_sum[i] *= scale;
-        }
-        if(sample_count) *sample_count = c->samples;
-        return FCGPU_OK;
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if(rgb_sum)
+            {
+                HIP_TRY(c, hipMemcpy(rgb_sum, c->film, sizeof(double) * c->film_elems, hipMemcpyDeviceToHost));
+                // beta0 = W*H (perspective_camera.hpp:64-68) is applied here instead of per sample
+                const double scale = static_cast<double>(c->flat.width) * static_cast<double>(c->flat.height);
+                for(uint64_t i = 0; i < c->film_elems; ++i) rgb_sum[i] *= scale;
+            }
+            if(sample_count) *sample_count = c->samples;
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_film_device_ptr(fcgpu_ctx* c, void** rgb_dev, uint64_t* bytes)
@@ -794,29 +839,31 @@ extern "C"
 
     int fcgpu_get_counters(fcgpu_ctx* c, fcgpu_counters* out)
     {
-        if(!c || !out) return fail(c, FCGPU_E_INVALID, "null argument");
-        HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        unsigned long long st[ST_COUNT];
-        HIP_TRY(c, hipMemcpy(st, c->stats, sizeof(st), hipMemcpyDeviceToHost));
-        std::memset(out, 0, sizeof(*out));
-        out->samples = c->samples;
-        out->closest_rays = st[ST_CLOSEST];
-        out->shadow_rays = st[ST_SHADOW];
-        out->shadow_occluded = st[ST_OCCLUDED];
-        out->nan_samples = st[ST_NAN];
-        out->stack_overflows = st[ST_STACK_OVERFLOW];
-        out->bvh_nodes = c->flat.nodes.size();
-        out->primitives = c->flat.prim_info.size();
-        out->kernel_launches = c->launches;
-        out->reserved[0] = st[ST_MEDIUM_OVERFLOW];
-        out->reserved[1] = c->flat.max_stack;
-        out->reserved[2] = c->flat.binary_nodes;
-        out->reserved[3] = st[ST_NODES];
-        out->reserved[4] = st[ST_PRIMS];
-        out->reserved[5] = st[ST_STACK_SPILL];
-        out->reserved[6] = c->flatten_us;
-        return FCGPU_OK;
+        return guarded(c, [&]() -> int {
+            if(!c || !out) return fail(c, FCGPU_E_INVALID, "null argument");
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            unsigned long long st[ST_COUNT];
+            HIP_TRY(c, hipMemcpy(st, c->stats, sizeof(st), hipMemcpyDeviceToHost));
+            std::memset(out, 0, sizeof(*out));
+            out->samples = c->samples;
+            out->closest_rays = st[ST_CLOSEST];
+            out->shadow_rays = st[ST_SHADOW];
+            out->shadow_occluded = st[ST_OCCLUDED];
+            out->nan_samples = st[ST_NAN];
+            out->stack_overflows = st[ST_STACK_OVERFLOW];
+            out->bvh_nodes = c->flat.nodes.size();
+            out->primitives = c->flat.prim_info.size();
+            out->kernel_launches = c->launches;
+            out->reserved[0] = st[ST_MEDIUM_OVERFLOW];
+            out->reserved[1] = c->flat.max_stack;
+            out->reserved[2] = c->flat.binary_nodes;
+            out->reserved[3] = st[ST_NODES];
+            out->reserved[4] = st[ST_PRIMS];
+            out->reserved[5] = st[ST_STACK_SPILL];
+            out->reserved[6] = c->flatten_us;
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_reset_counters(fcgpu_ctx* c)
@@ -830,29 +877,35 @@ extern "C"
 
     int fcgpu_sync(fcgpu_ctx* c)
     {
-        if(!c) return FCGPU_E_INVALID;
-        HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        return FCGPU_OK;
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_set_profiling(fcgpu_ctx* c, int enabled)
     {
-        if(!c) return FCGPU_E_INVALID;
-        HIP_TRY(c, hipSetDevice(c->device));
-        drain_spans(c);
-        c->profiling = enabled != 0;
-        return FCGPU_OK;
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            HIP_TRY(c, hipSetDevice(c->device));
+            drain_spans(c);
+            c->profiling = enabled != 0;
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_get_stage_times(fcgpu_ctx* c, fcgpu_stage_times* out)
     {
-        if(!c || !out) return fail(c, FCGPU_E_INVALID, "null argument");
-        HIP_TRY(c, hipSetDevice(c->device));
-        drain_spans(c);
-        *out = c->stage_times;
-        c->stage_times = fcgpu_stage_times{};
-        return FCGPU_OK;
+        return guarded(c, [&]() -> int {
+            if(!c || !out) return fail(c, FCGPU_E_INVALID, "null argument");
+            HIP_TRY(c, hipSetDevice(c->device));
+            drain_spans(c);
+            *out = c->stage_times;
+            c->stage_times = fcgpu_stage_times{};
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_stream(fcgpu_ctx* c, void** stream)
@@ -864,22 +917,24 @@ extern "C"
 
     int fcgpu_export_image(fcgpu_ctx* c, const char* name)
     {
-        if(!c || !name) return fail(c, FCGPU_E_INVALID, "null argument");
-        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
-        std::vector<double> sum(c->film_elems);
-        uint64_t count = 0;
-        int rc = fcgpu_read_film(c, sum.data(), &count);
-        if(rc) return rc;
-        std::string path = std::string(name) + ".raw";
-        FILE* f = std::fopen(path.c_str(), "wb");
-        if(!f) return fail(c, FCGPU_E_INVALID, "cannot open " + path);
-        std::vector<float> row(3 * static_cast<size_t>(c->flat.width));
-        for(int y = 0; y < c->flat.height; ++y)
-        {
-            for(size_t i = 0; i < row.size(); ++i) row[i] = static_cast<float>(sum[static_cast<size_t>(y) * row.size() + i] / static_cast<double>(count));
-            std::fwrite(row.data(), sizeof(float), row.size(), f);
-        }
-        std::fclose(f);
-        return FCGPU_OK;
+        return guarded(c, [&]() -> int {
+            if(!c || !name) return fail(c, FCGPU_E_INVALID, "null argument");
+            if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+            std::vector<double> sum(c->film_elems);
+            uint64_t count = 0;
+            int rc = fcgpu_read_film(c, sum.data(), &count);
+            if(rc) return rc;
+            std::string path = std::string(name) + ".raw";
+            FILE* f = std::fopen(path.c_str(), "wb");
+            if(!f) return fail(c, FCGPU_E_INVALID, "cannot open " + path);
+            std::vector<float> row(3 * static_cast<size_t>(c->flat.width));
+            for(int y = 0; y < c->flat.height; ++y)
+            {
+                for(size_t i = 0; i < row.size(); ++i) row[i] = static_cast<float>(sum[static_cast<size_t>(y) * row.size() + i] / static_cast<double>(count));
+                std::fwrite(row.data(), sizeof(float), row.size(), f);
+            }
+            std::fclose(f);
+            return FCGPU_OK;
+        });
     }
 }

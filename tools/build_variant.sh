@@ -1,0 +1,11 @@
+#!/bin/bash
+# Builds a variant of libfcgpu.so with extra -D flags for same-box A/B timing (tools/ab_perf.py).
+# usage: tools/build_variant.sh NAME [-DFLAG=V ...]   ->  ray-tracing_amd/csrc/build/var/libfcgpu_NAME.so
+set -e
+cd "$(dirname "$0")/../ray-tracing_amd/csrc"
+name=$1; shift
+make -s all >/dev/null
+mkdir -p build/var
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -Wall -Wno-unused-function "$@" -c -o build/var/fc_kernels_$name.o fc_kernels.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/var/libfcgpu_$name.so build/var/fc_kernels_$name.o build/fc_lbvh.o build/fc_api.o build/fc_host.o
+echo build/var/libfcgpu_$name.so
