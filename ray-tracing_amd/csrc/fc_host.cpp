@@ -1093,6 +1093,19 @@ namespace fcg
             er.light = -1;
             er.flags = (s.kind == FCGPU_SURFACE_MESH && s.has_normals ? 1u : 0u) | (s.kind == FCGPU_SURFACE_MESH && s.has_uvs ? 2u : 0u);
 
+            // TriRec::entity carries, above ENTITY_MASK, the queue key of a hit when nothing else decides it: no medium
+            // boundary, one constant lobe (k_extend then skips the entity -> material -> lobe loads)
+            if(ei > ENTITY_MASK)
+            {
+                err = "more than 2^24 entities";
+                return FCGPU_E_LIMIT;
+            }
+            uint32_t key_hint = KEY_HINT_NONE;
+            {
+                const MaterialRec& m = out.materials[static_cast<size_t>(e.material)];
+                if(er.medium == 0 && !m.textured && m.lobe_count == 1) key_hint = static_cast<uint32_t>(lobes[static_cast<size_t>(m.first_lobe)].type);
+            }
+
             uint32_t first_prim = static_cast<uint32_t>(kind_index.size());
             LightD light{};
             light.entity = static_cast<int32_t>(ei);
@@ -1200,7 +1213,7 @@ namespace fcg
                     std::memcpy(tr.v2, v[2], 12);
                     uint32_t prim = first_prim + t;
                     tr.prim = prim;
-                    tr.entity = ei;
+                    tr.entity = ei | (key_hint << 24);
                     tr.attr = INVALID_U32;
                     if(s.has_normals || s.has_uvs)
                     {

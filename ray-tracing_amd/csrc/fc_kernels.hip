@@ -316,12 +316,13 @@ namespace fcg
                     Vec4<R> h0{}, h1{};
                     bool recast = false;
                     bool alive = false;
-                    uint32_t prim = INVALID_U32, entity = 0;
+                    uint32_t prim = INVALID_U32, entity = 0, key_hint = KEY_HINT_NONE;
                     vec3<R> p{}, nrm{};
                     if(T.pk != INVALID_U32)
                     {
-                        hit_point(S, T.rc, T.pk, T.t_max, T.b0, T.b1, p, nrm, prim, entity);
-                        const uint32_t med = static_cast<uint32_t>(S.entities[entity].medium);
+                        hit_point(S, T.rc, T.pk, T.t_max, T.b0, T.b1, p, nrm, prim, entity, key_hint);
+                        // a hinted triangle is no medium boundary and has one constant lobe: the record just loaded decides
+                        const uint32_t med = key_hint != KEY_HINT_NONE ? 0u : static_cast<uint32_t>(S.entities[entity].medium);
                         const uint32_t top = medium_top(S, ms);
                         if(med == 0u)
                         {
@@ -378,6 +379,10 @@ namespace fcg
                             if(last)
                             {
                                 key = Q_FINAL;
+                            }
+                            else if(key_hint != KEY_HINT_NONE)
+                            {
+                                key = static_cast<int>(key_hint);  // single constant lobe: any draw picks lobe 0
                             }
                             else
                             {
@@ -582,7 +587,7 @@ namespace fcg
         {
             // mesh_surface.hpp:211-248
             const TriRec T = S.tris[idx];
-            sp.entity = T.entity;
+            sp.entity = T.entity & ENTITY_MASK;
             vec3<R> p0 = ldv<R>(T.v0), p1 = ldv<R>(T.v1), p2 = ldv<R>(T.v2);
             vec3<R> dp02 = p0 - p2, dp12 = p1 - p2;
             sp.f.ng = normalize(cross(dp02, dp12));
@@ -601,7 +606,7 @@ namespace fcg
                 R d12x = R(A.uv1[0]) - R(A.uv2[0]), d12y = R(A.uv1[1]) - R(A.uv2[1]);
                 R det = d02x * d12y - d02y * d12x;
                 dpdu = (d12y * dp02 - d02y * dp12) / det;
-                if(S.entities[T.entity].flags & 1u)
+                if(S.entities[sp.entity].flags & 1u)
                     sp.f.ns = normalize(b0 * ldv<R>(A.n0) + b1 * ldv<R>(A.n1) + b2 * ldv<R>(A.n2));
                 else
                     sp.f.ns = sp.f.ng;
@@ -1100,8 +1105,8 @@ namespace fcg
                 if(hit)
                 {
                     vec3<R> p, nrm;
-                    uint32_t prim, entity;
-                    hit_point(S, rc, pk, t, b0, b1, p, nrm, prim, entity);
+                    uint32_t prim, entity, key_hint;
+                    hit_point(S, rc, pk, t, b0, b1, p, nrm, prim, entity, key_hint);
                     h.t = static_cast<double>(t);
                     h.b0 = static_cast<double>(b0);
                     h.b1 = static_cast<double>(b1);

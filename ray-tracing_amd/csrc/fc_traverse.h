@@ -538,8 +538,9 @@ namespace fcg
     // geometry of a hit: world position and geometric normal, as the reference's raycast_surface_point builds them
     template<typename R>
     FC_D void hit_point(const SceneDev<R>& S, const RayCtx<R>& rc, uint32_t pk, R t, R b0, R b1, vec3<R>& p, vec3<R>& n,
-                        uint32_t& prim, uint32_t& entity)
+                        uint32_t& prim, uint32_t& entity, uint32_t& key_hint)
     {
+        key_hint = KEY_HINT_NONE;
         uint32_t kind = pk >> 30, idx = pk & 0x3FFFFFFFu;
         if(kind == KIND_TRI)
         {
@@ -549,7 +550,8 @@ namespace fcg
             p = b0 * p0 + b1 * p1 + b2 * p2;              // mesh_surface.hpp:211
             n = normalize(cross(p0 - p2, p1 - p2));       // :212-213, 227
             prim = T.prim;
-            entity = T.entity;
+            entity = T.entity & ENTITY_MASK;
+            key_hint = T.entity >> 24;
         }
         else
         {

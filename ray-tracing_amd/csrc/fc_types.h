@@ -51,10 +51,11 @@ namespace fcg
     struct alignas(16) TriRec
     {
         float v0[3]; uint32_t prim;    // global primitive id
-        float v1[3]; uint32_t entity;
+        float v1[3]; uint32_t entity;  // entity index (ENTITY_MASK) | key hint << 24 (KEY_HINT_NONE = look the material up)
         float v2[3]; uint32_t attr;    // index of vertex attributes (normals/uvs) or INVALID_U32
     };
     static_assert(sizeof(TriRec) == 48, "TriRec is 3 x 16 B");
+    constexpr uint32_t ENTITY_MASK = 0x00FFFFFFu, KEY_HINT_NONE = 0xFFu;
 
     struct TriAttr  // per-triangle vertex attributes, only for meshes that carry them
     {
