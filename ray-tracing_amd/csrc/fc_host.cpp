@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -460,10 +461,18 @@ namespace fcg
             FlatScene& out_;
             std::vector<std::pair<uint32_t, uint32_t>> range_;
             std::vector<char> tri_only_;
+            uint32_t max_leaf_ = leaf_limit();
+
+            static uint32_t leaf_limit()  // FCGPU_MAX_LEAF (development knob): 1 .. MAX_LEAF_PRIMS
+            {
+                const char* e = std::getenv("FCGPU_MAX_LEAF");
+                const int v = e ? std::atoi(e) : MAX_LEAF_PRIMS;
+                return static_cast<uint32_t>(std::min(std::max(v, 1), MAX_LEAF_PRIMS));
+            }
 
             bool is_leafish(uint32_t b) const
             {
-                return !bin_.nodes[b].interior || (tri_only_[b] && range_[b].second <= static_cast<uint32_t>(MAX_LEAF_PRIMS));
+                return !bin_.nodes[b].interior || (tri_only_[b] && range_[b].second <= max_leaf_);
             }
 
             // leaf runs covering the primitives of binary node b, inserted at `at`
@@ -476,7 +485,7 @@ namespace fcg
                     uint32_t kind = order_ki_[k] >> 30;
                     uint32_t n = 1;
                     if(kind == KIND_TRI)
-                        while(k + n < end && n < static_cast<uint32_t>(MAX_LEAF_PRIMS) && (order_ki_[k + n] >> 30) == KIND_TRI) ++n;
+                        while(k + n < end && n < max_leaf_ && (order_ki_[k + n] >> 30) == KIND_TRI) ++n;
                     BoxF box;
                     for(uint32_t q = k; q < k + n; ++q) box.grow(order_box_[q]);
                     kids.insert(kids.begin() + at + added, WideChild{box, true, 0u, kind, order_ki_[k] & 0x3FFFFFFFu, n});

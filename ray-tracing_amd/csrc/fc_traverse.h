@@ -420,12 +420,12 @@ namespace fcg
                 n_prims += count;
                 // all records of the leaf are requested before the first test: one memory latency per
                 // leaf instead of one per triangle
-                TriRec tr[4];
+                TriRec tr[MAX_LEAF_PRIMS];
 #pragma unroll
-                for(uint32_t j = 0; j < 4u; ++j)
+                for(uint32_t j = 0; j < static_cast<uint32_t>(MAX_LEAF_PRIMS); ++j)
                     if(j < count) tr[j] = S.tris[first + j];
 #pragma unroll
-                for(uint32_t j = 0; j < 4u; ++j)
+                for(uint32_t j = 0; j < static_cast<uint32_t>(MAX_LEAF_PRIMS); ++j)
                 {
                     R t, b0, b1;
                     if(j < count && !stop && tri_intersect(tr[j], T.rc, T.t_max, t, b0, b1))
