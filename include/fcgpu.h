@@ -215,12 +215,16 @@ typedef struct fcgpu_scene_desc {
 #define FCGPU_INTEGRATOR_BSDF 0 /* forward_bsdf_integrator */
 #define FCGPU_INTEGRATOR_MIS 1  /* forward_mis_integrator  */
 
-/* Who builds the binary hierarchy that is then collapsed to the 4-wide device layout.
- * HOST_SAH: the reference's own top-down SAH build (bvh_acceleration_structure.hpp:228-365), in its order.
+/* Who builds the binary hierarchy that is then collapsed to the 4-wide device layout. The hits do not depend on it
+ * (exact t ties aside); the number of node steps per ray does.
+ * HOST_SAH (default): the reference's top-down SAH build (bvh_acceleration_structure.hpp:228-365) with a wider split
+ *   search: 32 buckets on each of the three axes instead of 12 on the longest one.
  * DEVICE_LBVH: Morton-order linear BVH built on the GPU, for very large meshes where the host recursion
- * dominates scene upload; same hits (exact t ties aside), lower tree quality. */
+ *   dominates scene upload; lower tree quality.
+ * HOST_REFERENCE: the reference's build with its own split search, i.e. its tree and primitive order. */
 #define FCGPU_BVH_HOST_SAH 0
 #define FCGPU_BVH_DEVICE_LBVH 1
+#define FCGPU_BVH_HOST_REFERENCE 2
 
 typedef struct fcgpu_options {
     int32_t precision;          /* FCGPU_PRECISION_* */

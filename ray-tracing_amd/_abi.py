@@ -14,7 +14,7 @@ FILTER_BOX, FILTER_BILINEAR = 0, 1
 TEXTURE_IMAGE, TEXTURE_CHECKER = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 INTEGRATOR_BSDF, INTEGRATOR_MIS = 0, 1
-BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
+BVH_HOST_SAH, BVH_DEVICE_LBVH, BVH_HOST_REFERENCE = 0, 1, 2
 
 E_INVALID, E_HIP, E_NOSCENE, E_LIMIT, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 

@@ -657,7 +657,7 @@ extern "C"
             if(!c || !opt) return fail(c, FCGPU_E_INVALID, "null argument");
             if(opt->precision != FCGPU_PRECISION_F32 && opt->precision != FCGPU_PRECISION_F64) return fail(c, FCGPU_E_INVALID, "unknown precision");
             if(opt->max_paths_in_flight != 0 && opt->max_paths_in_flight < 256) return fail(c, FCGPU_E_INVALID, "max_paths_in_flight < 256");
-            if(opt->bvh_builder != FCGPU_BVH_HOST_SAH && opt->bvh_builder != FCGPU_BVH_DEVICE_LBVH) return fail(c, FCGPU_E_INVALID, "unknown bvh_builder");
+            if(opt->bvh_builder > FCGPU_BVH_HOST_REFERENCE) return fail(c, FCGPU_E_INVALID, "unknown bvh_builder");
             c->opt = *opt;
             return FCGPU_OK;
         });
@@ -691,7 +691,8 @@ extern "C"
                 return lbvh_build(c->stream, boxes, tree, e);
             };
             const auto t_build = std::chrono::steady_clock::now();
-            int rc = flatten_scene(*d, flat, err, c->opt.bvh_builder == FCGPU_BVH_DEVICE_LBVH ? &on_device : nullptr);
+            int rc = flatten_scene(*d, flat, err, c->opt.bvh_builder == FCGPU_BVH_DEVICE_LBVH ? &on_device : nullptr,
+                                   c->opt.bvh_builder == FCGPU_BVH_HOST_REFERENCE);
             c->flatten_us = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_build).count());
             if(rc != FCGPU_OK) return fail(c, rc, err);
 

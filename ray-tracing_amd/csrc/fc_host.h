@@ -72,6 +72,8 @@ namespace fcg
     using HierarchyBuilder = std::function<int(const std::vector<float>& boxes, LbvhTree& out, std::string& err)>;
 
     // Returns FCGPU_OK or a negative error code with a message in `err`. `device_builder`: build the binary hierarchy
-    // there instead of with the host's reference-order SAH builder (scenes of fewer than 2 primitives always use the host).
-    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err, const HierarchyBuilder* device_builder = nullptr);
+    // there instead of with the host's SAH builder (scenes of fewer than 2 primitives always use the host).
+    // `reference_split_rule`: the host builder searches splits exactly as the reference does (FCGPU_BVH_HOST_REFERENCE).
+    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err, const HierarchyBuilder* device_builder = nullptr,
+                      bool reference_split_rule = false);
 }

@@ -114,10 +114,11 @@ class GpuContext:
         self.close()
 
     def set_options(self, precision="f32", epsilon=0.0, max_paths_in_flight=0, sort_materials=True, bvh_builder="host"):
-        """bvh_builder: "host" = the reference's SAH build on the host, "device" = linear BVH built on the GPU."""
+        """bvh_builder: "host" = SAH build on the host (three-axis split search), "device" = linear BVH built on the GPU,
+        "reference" = host SAH build with the reference's own split search (its tree)."""
         o = A.Options(precision=A.PRECISION_F64 if precision == "f64" else A.PRECISION_F32,
                       sort_materials=int(sort_materials), epsilon=epsilon, max_paths_in_flight=max_paths_in_flight,
-                      bvh_builder=A.BVH_DEVICE_LBVH if bvh_builder == "device" else A.BVH_HOST_SAH)
+                      bvh_builder={"host": A.BVH_HOST_SAH, "device": A.BVH_DEVICE_LBVH, "reference": A.BVH_HOST_REFERENCE}[bvh_builder])
         self._check(self.lib.fcgpu_set_options(self.h, C.byref(o)))
 
     def upload_scene(self, scene):

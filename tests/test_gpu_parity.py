@@ -145,17 +145,21 @@ def test_converged_image_relmse():
     assert relmse <= 2e-3
 
 
-# ------------------------------------------------------------------ the hierarchy built on the device (FCGPU_BVH_DEVICE_LBVH)
+# ------------------------------------------------------------------ the other hierarchy builders (FCGPU_BVH_DEVICE_LBVH,
+# FCGPU_BVH_HOST_REFERENCE; every other test runs on the default, FCGPU_BVH_HOST_SAH)
+@pytest.mark.parametrize("builder", ["device", "reference"])
 @pytest.mark.parametrize("name", RAY_FIXTURES)
-def test_device_built_bvh_returns_the_reference_hits(name):
-    """Any valid BVH finds the same closest hit: the linear BVH built on the GPU must give the reference's
-    primitive ids and distances on the golden ray sets, like the host-built one."""
+def test_other_builders_return_the_reference_hits(name, builder):
+    """Any valid BVH finds the same closest hit: the linear BVH built on the GPU and the host build with the
+    reference's own split rule must give the reference's primitive ids and distances on the golden ray sets."""
     z, scene = load_rays(name)
-    with make_ctx(scene, "f64", bvh_builder="device") as ctx:
+    with make_ctx(scene, "f64", bvh_builder=builder) as ctx:
         hits = ctx.trace_closest(z["rays"])
         anyh = ctx.trace_any(z["rays"])
         c = ctx.counters()
-    assert c.stack_overflows == 0 and c.reserved[2] == 2 * scene.primitive_total() - 1  # one primitive per binary leaf
+    assert c.stack_overflows == 0
+    if builder == "device":
+        assert c.reserved[2] == 2 * scene.primitive_total() - 1  # one primitive per binary leaf
     ref_prim = z["bvh_prim"]
     mismatch = hits["prim"] != ref_prim
     assert mismatch.mean() <= 1e-4, f"prim id mismatches {mismatch.sum()} / {len(ref_prim)}"
@@ -164,10 +168,11 @@ def test_device_built_bvh_returns_the_reference_hits(name):
     assert (anyh != z["any_hit"]).mean() <= 1e-4
 
 
+@pytest.mark.parametrize("builder", ["device", "reference"])
 @pytest.mark.parametrize("name", ["room_t4", "zoo", "mask", "nested_rough"])
-def test_device_built_bvh_radiance_f64_matches_reference(name):
+def test_other_builders_radiance_f64_matches_reference(name, builder):
     z, scene = load_film(name)
-    with make_ctx(scene, "f64", bvh_builder="device") as ctx:
+    with make_ctx(scene, "f64", bvh_builder=builder) as ctx:
         ctx.set_sampler(int(z["seed"]), stratified=film_stratified(z))
         ctx.render_pass(0, int(z["spp"]), A.INTEGRATOR_MIS, int(z["max_path_length"]), True)
         rgb, n = ctx.read_film()
@@ -177,12 +182,13 @@ def test_device_built_bvh_radiance_f64_matches_reference(name):
     assert c.closest_rays == int(z["mis_rays"][0])
 
 
-def test_device_and_host_built_bvh_agree_on_a_large_mesh():
-    """196 608 wall triangles in fp32: both hierarchies cast the same rays and render the same image up to the few
-    paths whose exact-tie hits (shared triangle edges) resolve to the neighbouring triangle."""
+def test_all_builders_agree_on_a_large_mesh():
+    """196 608 wall triangles in fp32: the three hierarchies cast the same rays and render the same image up to the few
+    paths whose exact-tie hits (shared triangle edges) resolve to the neighbouring triangle; the default build takes
+    the fewest node steps per ray."""
     scene = S.room(width=160, height=90, tess=128)
     out = {}
-    for builder in ("host", "device"):
+    for builder in ("host", "device", "reference"):
         with make_ctx(scene, "f32", bvh_builder=builder) as ctx:
             ctx.set_sampler(5)
             ctx.render_pass(0, 4)
@@ -191,10 +197,11 @@ def test_device_and_host_built_bvh_agree_on_a_large_mesh():
             out[builder] = (rgb / n, c.closest_rays, c.reserved[3] / (c.closest_rays + c.shadow_rays), c.reserved[6])
             assert c.stack_overflows == 0 and c.nan_samples == 0
     print({k: dict(node_steps_per_ray=round(v[2], 2), flatten_ms=v[3] / 1e3) for k, v in out.items()})
-    a, b = out["host"][0], out["device"][0]
-    rel = pixel_rel_err(b, a)
-    assert np.median(rel) <= 1e-6 and (rel <= 1e-2).mean() >= 0.98
-    assert abs(int(out["host"][1]) - int(out["device"][1])) <= 1e-3 * out["host"][1]
+    for other in ("device", "reference"):
+        rel = pixel_rel_err(out[other][0], out["host"][0])
+        assert np.median(rel) <= 1e-6 and (rel <= 1e-2).mean() >= 0.98, other
+        assert abs(int(out["host"][1]) - int(out[other][1])) <= 1e-3 * out["host"][1], other
+        assert out["host"][2] < out[other][2], other
 
 
 @pytest.mark.parametrize("seed", range(12))

@@ -154,6 +154,10 @@ def test_error_codes():
     with pytest.raises(R.FcgpuError) as e:
         ctx.set_sampler(0, stratified=0)
     assert e.value.code == A.E_INVALID
+    for field, value in (("bvh_builder", 3), ("precision", 9), ("max_paths_in_flight", 17)):
+        o = A.Options(precision=A.PRECISION_F32, sort_materials=1, epsilon=0.0, max_paths_in_flight=0, bvh_builder=A.BVH_HOST_SAH)
+        setattr(o, field, value)
+        assert lib.fcgpu_set_options(ctx.h, C.byref(o)) == A.E_INVALID, field
     h = C.c_void_p()
     assert lib.fcgpu_create(4096, C.byref(h)) == A.E_INVALID
     ctx.close()
