@@ -357,6 +357,19 @@ int fcgpu_stream(fcgpu_ctx* ctx, void** stream);
  * top row first, float32 RGB, no header, file `<name>.raw`. Synchronous.                     */
 int fcgpu_export_image(fcgpu_ctx* ctx, const char* name);
 
+/* Validates a scene description and builds its hierarchy on the host without touching a device: what the
+ * entity_scene constructor and bvh_acceleration_structure's build (bvh_acceleration_structure.hpp:10-24) do for the
+ * reference, as far as it can fail or be measured before rendering. `bvh_builder`: FCGPU_BVH_HOST_SAH or
+ * FCGPU_BVH_HOST_REFERENCE. On failure the message is fcgpu_last_error(NULL) of the calling thread.            */
+typedef struct fcgpu_scene_stats {
+    uint64_t primitives, triangles;
+    uint64_t binary_nodes, wide_nodes;
+    uint64_t max_stack;         /* worst-case traversal stack of the wide hierarchy */
+    uint64_t lobe_mask;         /* bit k: lobe type k occurs */
+    uint64_t reserved[2];
+} fcgpu_scene_stats;
+int fcgpu_check_scene(const fcgpu_scene_desc* scene, uint32_t bvh_builder, fcgpu_scene_stats* out);
+
 /* Library/ABI version: major*1000 + minor. */
 int fcgpu_version(void);
 

@@ -125,6 +125,11 @@ class Counters(C.Structure):
     ]
 
 
+class SceneStats(C.Structure):
+    _fields_ = [("primitives", C.c_uint64), ("triangles", C.c_uint64), ("binary_nodes", C.c_uint64), ("wide_nodes", C.c_uint64),
+                ("max_stack", C.c_uint64), ("lobe_mask", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+
+
 class StageTimes(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
 
@@ -145,4 +150,5 @@ EXPORTS = [
     "fcgpu_trace_closest_device", "fcgpu_trace_any_device", "fcgpu_clear_film", "fcgpu_read_film",
     "fcgpu_film_device_ptr", "fcgpu_add_sample_count", "fcgpu_get_counters", "fcgpu_reset_counters",
     "fcgpu_sync", "fcgpu_set_profiling", "fcgpu_get_stage_times", "fcgpu_stream", "fcgpu_export_image", "fcgpu_version",
+    "fcgpu_check_scene",
 ]

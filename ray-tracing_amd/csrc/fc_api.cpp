@@ -546,7 +546,46 @@ namespace
 
 extern "C"
 {
-    int fcgpu_version(void) { return 1001; }
+    int fcgpu_version(void) { return 1002; }
+
+    int fcgpu_check_scene(const fcgpu_scene_desc* d, uint32_t bvh_builder, fcgpu_scene_stats* out)
+    {
+        try
+        {
+            if(!d || (bvh_builder != FCGPU_BVH_HOST_SAH && bvh_builder != FCGPU_BVH_HOST_REFERENCE))
+            {
+                g_create_error = d ? "fcgpu_check_scene builds on the host: FCGPU_BVH_HOST_SAH or FCGPU_BVH_HOST_REFERENCE" : "null scene";
+                return FCGPU_E_INVALID;
+            }
+            FlatScene flat;
+            std::string err;
+            const int rc = flatten_scene(*d, flat, err, nullptr, bvh_builder == FCGPU_BVH_HOST_REFERENCE);
+            if(rc != FCGPU_OK)
+            {
+                g_create_error = err;
+                return rc;
+            }
+            if(out)
+            {
+                *out = fcgpu_scene_stats{};
+                out->primitives = flat.prim_info.size();
+                out->triangles = flat.tris.size();
+                out->binary_nodes = flat.binary_nodes;
+                out->wide_nodes = flat.nodes.size();
+                out->max_stack = flat.max_stack;
+                out->lobe_mask = flat.lobe_mask;
+            }
+            return FCGPU_OK;
+        }
+        catch(const std::bad_alloc&)
+        {
+            return FCGPU_E_NOMEM;
+        }
+        catch(...)
+        {
+            return FCGPU_E_INVALID;
+        }
+    }
 
     int fcgpu_create(int device, fcgpu_ctx** out)
     {

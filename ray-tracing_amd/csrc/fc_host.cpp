@@ -312,6 +312,14 @@ namespace fcg
                         auto it = std::partition(refs_.begin() + begin, refs_.begin() + end,
                                                  [axis, partition_point](const PrimRef& a) { return a.centroid[axis] < partition_point; });
                         middle = static_cast<uint32_t>(std::distance(refs_.begin(), it));
+                        if(middle == begin || middle == end)
+                        {
+                            // the float partition point fell outside the occupied buckets (a centroid range of a few
+                            // ulps): split at the median instead, or the recursion would never end
+                            middle = begin + count / 2;
+                            std::nth_element(refs_.begin() + begin, refs_.begin() + middle, refs_.begin() + end,
+                                             [axis](const PrimRef& a, const PrimRef& b) { return a.centroid[axis] < b.centroid[axis]; });
+                        }
                     }
                     else
                     {

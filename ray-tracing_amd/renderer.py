@@ -60,6 +60,7 @@ def load_library():
         "fcgpu_stream": (i32, [vp, P(vp)]),
         "fcgpu_export_image": (i32, [vp, C.c_char_p]),
         "fcgpu_version": (i32, []),
+        "fcgpu_check_scene": (i32, [P(A.SceneDesc), u32, P(A.SceneStats)]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -67,6 +68,17 @@ def load_library():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def check_scene(scene, bvh_builder="host"):
+    """Validates `scene` and builds its hierarchy on the host, no device needed (fcgpu_check_scene): SceneStats."""
+    lib = load_library()
+    desc = scene.desc()
+    st = A.SceneStats()
+    rc = lib.fcgpu_check_scene(C.byref(desc), {"host": A.BVH_HOST_SAH, "reference": A.BVH_HOST_REFERENCE}[bvh_builder], C.byref(st))
+    if rc != 0:
+        raise FcgpuError(rc, (lib.fcgpu_last_error(None) or b"").decode())
+    return st
 
 
 class _DeviceArray:

@@ -1,6 +1,9 @@
 """Host-side logic that needs no GPU: scene descriptions, tile sharding, sampler statistics."""
 import os
+import ctypes as C
+
 import numpy as np
+import pytest
 
 from common import A, R, S
 from oracle import pyref
@@ -70,3 +73,27 @@ def test_fast_div_matches_hardware_divide(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O2", "-o", str(exe), src], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
+
+
+def test_check_scene_builds_the_hierarchy_without_a_device():
+    """fcgpu_check_scene: validation + host BVH build, no GPU. The mask stand-in at detail 256 has centroid ranges of a
+    few ulps on the minor axes, where the float partition point of a bucket split can leave one side empty: the
+    builder has to fall back to the median there instead of recursing for ever."""
+    sc = S.room(width=64, height=36, tess=16)
+    for builder in ("host", "reference"):
+        st = R.check_scene(sc, builder)
+        assert st.primitives == sc.primitive_total() and st.triangles == sc.primitive_total() - 3  # three spheres
+        assert st.wide_nodes * 4 >= st.primitives / 2 and 0 < st.max_stack <= 30
+        assert st.lobe_mask & 1  # lambertian walls
+    big = S.mask_scene(width=60, height=90, detail=256, texture_size=16)
+    a, b = R.check_scene(big, "host"), R.check_scene(big, "reference")
+    assert a.primitives == b.primitives == big.primitive_total() and a.binary_nodes == b.binary_nodes
+    bad = S.room_planes(32, 18)
+    bad.entities[0].material = 99
+    with pytest.raises(R.FcgpuError) as e:
+        R.check_scene(bad)
+    assert e.value.code == A.E_INVALID and "entity" in str(e.value)
+    lib = R.load_library()
+    assert lib.fcgpu_check_scene(None, A.BVH_HOST_SAH, None) == A.E_INVALID
+    desc = sc.desc()
+    assert lib.fcgpu_check_scene(C.byref(desc), A.BVH_DEVICE_LBVH, None) == A.E_INVALID
