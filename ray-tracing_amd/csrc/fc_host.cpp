@@ -281,19 +281,20 @@ namespace fcg
                             buckets[bi].count += 1;
                             buckets[bi].box.grow(refs_[i].box);
                         }
+                        // right[i] = union of buckets i+1 .. (min / max are exact: the order of the unions does not matter)
+                        Bucket right[32]{};
+                        for(int i = bucket_count - 2; i >= 0; --i)
+                        {
+                            right[i] = right[i + 1];
+                            right[i].box.grow(buckets[i + 1].box);
+                            right[i].count += buckets[i + 1].count;
+                        }
+                        Bucket b0{};
                         for(int i = 0; i < bucket_count - 1; ++i)
                         {
-                            Bucket b0{}, b1{};
-                            for(int j = 0; j <= i; ++j)
-                            {
-                                b0.box.grow(buckets[j].box);
-                                b0.count += buckets[j].count;
-                            }
-                            for(int j = i + 1; j < bucket_count; ++j)
-                            {
-                                b1.box.grow(buckets[j].box);
-                                b1.count += buckets[j].count;
-                            }
+                            b0.box.grow(buckets[i].box);
+                            b0.count += buckets[i].count;
+                            const Bucket& b1 = right[i];
                             const double cost = 0.125 + (b0.count * b0.box.area() + b1.count * b1.box.area()) / box.area();
                             if(min_index < 0 || cost < min_cost)
                             {
