@@ -97,3 +97,15 @@ def test_check_scene_builds_the_hierarchy_without_a_device():
     assert lib.fcgpu_check_scene(None, A.BVH_HOST_SAH, None) == A.E_INVALID
     desc = sc.desc()
     assert lib.fcgpu_check_scene(C.byref(desc), A.BVH_DEVICE_LBVH, None) == A.E_INVALID
+
+
+def test_threaded_bvh_build_gives_the_sequential_tree(monkeypatch):
+    """Above 65 536 primitives the host build runs ranges of the tree on several threads and splices them into
+    depth-first order: node counts and the worst-case stack must not depend on the thread count."""
+    sc = S.room(width=64, height=36, tess=80)  # 76 899 primitives
+    stats = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("FCGPU_BUILD_THREADS", threads)
+        st = R.check_scene(sc, "host")
+        stats.append((st.primitives, st.binary_nodes, st.wide_nodes, st.max_stack))
+    assert stats[0] == stats[1] == stats[2] and stats[0][0] == sc.primitive_total()
