@@ -732,7 +732,6 @@ namespace fcg
                 uint32_t ms = unpack_word(h1.y);
                 PathState<R> st = Q.state[path];
                 vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
-                vec3<R> Li{st.Li[0], st.Li[1], st.Li[2]};
                 const vec3<R> p1{st.p1[0], st.p1[1], st.p1[2]};
                 const vec3<R> w12{st.w[0], st.w[1], st.w[2]};  // direction that reached this hit
                 SurfacePoint<R> sp = make_surface_point(S, hit_word_kind(hw), hit_word_index(hw), vec3<R>{h0.x, h0.y, h0.z}, h0.w, h1.x);
@@ -750,11 +749,14 @@ namespace fcg
                 }
                 if(ent.light >= 0)
                 {
+                    // an emitter was hit: its term goes straight to the path's radiance column (a rare, exclusive RMW:
+                    // a path is in one queue entry per launch)
                     const LightRec<R>& Lt = S.lights[ent.light];
                     vec3<R> Le = dot(ng, -w12) > R(0) ? rgb(Lt.Le) : vec3<R>{R(0), R(0), R(0)};  // const_diffuse_area_light.hpp:20-26
+                    vec3<R> add;
                     if((st.flags & 1u) || !mis)
                     {
-                        Li = Li + beta * Le;  // :40-43, :193-196
+                        add = beta * Le;  // :40-43, :193-196
                     }
                     else
                     {
@@ -763,8 +765,13 @@ namespace fcg
                         vec3<R> d12 = sp.p - p1;
                         R pdf_bsdf_p2 = st.pdf * r_abs(dot(ng, w12)) / dot(d12, d12);
                         R weight = power_heuristic(pdf_bsdf_p2, pdf_light_p2);
-                        Li = Li + weight * (beta * Le);  // :140-147
+                        add = weight * (beta * Le);  // :140-147
                     }
+                    Vec4<R> acc = Q.li_shadow[path];
+                    acc.x += add.x;
+                    acc.y += add.y;
+                    acc.z += add.z;
+                    Q.li_shadow[path] = acc;
                 }
 
                 bool alive = false;
@@ -901,15 +908,14 @@ namespace fcg
                     }
                 }
 
-                st.beta[0] = beta.x; st.beta[1] = beta.y; st.beta[2] = beta.z;
-                st.Li[0] = Li.x; st.Li[1] = Li.y; st.Li[2] = Li.z;
-                if(alive)
+                if(alive)  // a path that ends here leaves nothing behind: what it gathered is in the radiance column
                 {
+                    st.beta[0] = beta.x; st.beta[1] = beta.y; st.beta[2] = beta.z;
                     st.pdf = pdf_w12;
                     st.p1[0] = sp.p.x; st.p1[1] = sp.p.y; st.p1[2] = sp.p.z;
                     st.w[0] = wn.x; st.w[1] = wn.y; st.w[2] = wn.z;
+                    Q.state[path] = st;
                 }
-                Q.state[path] = st;
             }
             if constexpr(KEY != Q_FINAL)
             {
@@ -942,7 +948,7 @@ namespace fcg
             Vec4<R> h1 = Q.hit_c1[Q.hit_idx[Q_MISS][i]];
             uint32_t prim, path;
             unpack_ids(h1, prim, path);
-            PathState<R>& st = Q.state[path];
+            const PathState<R> st = Q.state[path];
             vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
             const vec3<R> w{st.w[0], st.w[1], st.w[2]};  // direction of the ray that left the scene
             vec3<R> env = env_Li(S, w);
@@ -959,9 +965,11 @@ namespace fcg
             }
             if(weight != R(0) || weight != weight)
             {
-                st.Li[0] += weight * beta.x * env.x;
-                st.Li[1] += weight * beta.y * env.y;
-                st.Li[2] += weight * beta.z * env.z;
+                Vec4<R> acc = Q.li_shadow[path];
+                acc.x += weight * beta.x * env.x;
+                acc.y += weight * beta.y * env.y;
+                acc.z += weight * beta.z * env.z;
+                Q.li_shadow[path] = acc;
             }
         }
     }
@@ -1044,9 +1052,8 @@ namespace fcg
             double r = out[0], g = out[1], b = out[2];
             for(uint32_t sl = 0; sl < B.nsamp; ++sl)
             {
-                const PathState<R>& st = Q.state[sl * B.npix + pp];
-                const Vec4<R> sh = Q.li_shadow[sl * B.npix + pp];
-                R x = st.Li[0] + sh.x, y = st.Li[1] + sh.y, z = st.Li[2] + sh.z;
+                const Vec4<R> sh = Q.li_shadow[sl * B.npix + pp];  // everything the path gathered
+                R x = sh.x, y = sh.y, z = sh.z;
                 if(!r_isfinite(x) || !r_isfinite(y) || !r_isfinite(z))  // perspective_camera.hpp:126-131
                 {
                     n_nan += 1;

@@ -315,21 +315,21 @@ namespace fcg
         return (m & 0x007FFFFFu) | (above << 23) | (below << 27);
     }
 
-    // per-path persistent state, AoS: 64 B in fp32 (one line), 128 B in fp64
+    // per-path persistent state, AoS: 48 B in fp32, 96 B in fp64. The radiance a path has gathered is NOT part of it: it
+    // lives in the Wavefront's `li_shadow` column, which only the hits that add to it touch (emitter and environment
+    // hits, unoccluded shadow rays), so a bounce moves 2 x 48 instead of 2 x 64 bytes of state.
     template<typename R>
     struct alignas(16) PathState
     {
         R beta[3];
         R pdf;        // pdf_w12 of the last BSDF sample (forward_mis_integrator.hpp:104)
-        R Li[3];
-        uint32_t flags;  // bit0: last lobe was delta (or camera segment): emitter hits un-weighted (in fp64 the compiler pads to 8)
         R p1[3];      // previous vertex (un-offset), for transmittance and the area-measure pdf
-        R pad1;
+        uint32_t flags;  // bit0: last lobe was delta (or camera segment): emitter hits un-weighted (in fp64 the compiler pads to 8)
         R w[3];       // direction of the segment that produced the current hit (w12)
         R pad2;
     };
 
-    static_assert(sizeof(PathState<float>) == 64 && sizeof(PathState<double>) == 128, "one path state = four 16-byte (32-byte) pieces");
+    static_assert(sizeof(PathState<float>) == 48 && sizeof(PathState<double>) == 96, "one path state = three 16-byte (32-byte) pieces");
 
     constexpr int WORK_RANGES = 8;
 
