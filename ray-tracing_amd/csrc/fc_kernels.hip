@@ -378,7 +378,9 @@ namespace fcg
                             uint32_t lobe = 0;
                             if(last)
                             {
-                                key = Q_FINAL;
+                                // the last vertex only gathers emitted light (forward_mis_integrator.hpp:128-147): a hit
+                                // on anything else ends the path here, without a hit record
+                                key = S.entities[entity].light >= 0 ? Q_FINAL : 0xFF;
                             }
                             else if(key_hint != KEY_HINT_NONE)
                             {
