@@ -206,7 +206,7 @@ namespace fcg
             Q.ray_c0[i] = c0;
             Q.ray_c1[i] = c1;
         }
-        if(blockIdx.x == 0 && threadIdx.x == 0) Q.counters->ray[B.parity] = n;
+        if(blockIdx.x == 0 && threadIdx.x == 0) Q.counters->ray[B.parity][0] = n;
     }
 
     // ------------------------------------------------------------------ extend
@@ -280,7 +280,7 @@ namespace fcg
         __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
         uint32_t* stack = stack_lds + threadIdx.x;
         unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
-        const uint32_t n = Q.counters->ray[B.parity];
+        const uint32_t n = Q.counters->ray[B.parity][0];
         uint32_t n_cast = 0, n_moverflow = 0, n_nodes = 0, n_prims = 0;
         StackStats n_overflow;
         const bool last = B.h >= B.max_len;
@@ -508,7 +508,10 @@ namespace fcg
 
     // material sort: index lists per queue key from hit_key[]. Each thread owns SORT_ITEMS consecutive
     // hits, so a block compacts BLOCK * SORT_ITEMS hits with ONE global atomic per key.
-    constexpr int SORT_ITEMS = 8;
+#ifndef FCG_SORT_ITEMS
+#define FCG_SORT_ITEMS 16
+#endif
+    constexpr int SORT_ITEMS = FCG_SORT_ITEMS;
 
     template<typename R>
     __global__ __launch_bounds__(BLOCK) void k_sort(Wavefront<R> Q, Batch B)
@@ -516,7 +519,7 @@ namespace fcg
         __shared__ uint32_t cnt_lds[Q_COUNT][WAVES];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const uint64_t lt = (1ull << lane) - 1ull;
-        const uint32_t n = Q.counters->ray[B.parity];
+        const uint32_t n = Q.counters->ray[B.parity][0];
         for(uint32_t base = blockIdx.x * (BLOCK * SORT_ITEMS); base < n; base += gridDim.x * (BLOCK * SORT_ITEMS))
         {
             // item j of this thread is hit  base + j * BLOCK + threadIdx.x  (coalesced byte loads)
@@ -550,7 +553,7 @@ namespace fcg
                 uint32_t total = 0;
 #pragma unroll
                 for(int w = 0; w < WAVES; ++w) total += cnt_lds[threadIdx.x][w];
-                uint32_t start = total ? atomicAdd(&Q.counters->hit[threadIdx.x], total) : 0u;
+                uint32_t start = total ? atomicAdd(&Q.counters->hit[threadIdx.x][0], total) : 0u;
 #pragma unroll
                 for(int w = 0; w < WAVES; ++w)
                 {
@@ -709,12 +712,12 @@ namespace fcg
         __shared__ uint32_t* q_ctr[2];
         if(threadIdx.x == 0)
         {
-            q_ctr[0] = &Q.counters->ray[B.parity ^ 1];
-            q_ctr[1] = &Q.counters->shadow;
+            q_ctr[0] = &Q.counters->ray[B.parity ^ 1][0];
+            q_ctr[1] = &Q.counters->shadow[0];
         }
         __syncthreads();
 
-        const uint32_t n = Q.counters->hit[KEY];
+        const uint32_t n = Q.counters->hit[KEY][0];
         const bool mis = B.integrator == FCGPU_INTEGRATOR_MIS;
         const uint32_t dim = 2u + (mis ? 6u : 3u) * static_cast<uint32_t>(B.h - 1);
         const uint32_t dim_u2 = dim + (mis ? 4u : 1u), dim_u1 = dim + (mis ? 5u : 2u);
@@ -943,7 +946,7 @@ namespace fcg
     template<typename R>
     __global__ __launch_bounds__(BLOCK) void k_miss(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
-        const uint32_t n = Q.counters->hit[Q_MISS];
+        const uint32_t n = Q.counters->hit[Q_MISS][0];
         const bool mis = B.integrator == FCGPU_INTEGRATOR_MIS;
         for(uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
         {
@@ -984,7 +987,7 @@ namespace fcg
         __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
         uint32_t* stack = stack_lds + threadIdx.x;
         unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
-        const uint32_t n = Q.counters->shadow;
+        const uint32_t n = Q.counters->shadow[0];
         uint32_t n_cast = 0, n_occ = 0, n_nodes = 0, n_prims = 0;
         StackStats n_overflow;
         WorkCursor W = work_begin();
@@ -1074,11 +1077,11 @@ namespace fcg
 
     __global__ void k_reset_counters(QueueCounters* c, int parity_to_keep)
     {
-        if(threadIdx.x < Q_COUNT) c->hit[threadIdx.x] = 0;
+        if(threadIdx.x < Q_COUNT) c->hit[threadIdx.x][0] = 0;
         if(threadIdx.x == 0)
         {
-            c->ray[parity_to_keep ^ 1] = 0;
-            c->shadow = 0;
+            c->ray[parity_to_keep ^ 1][0] = 0;
+            c->shadow[0] = 0;
         }
         if(threadIdx.x < WORK_RANGES)
         {

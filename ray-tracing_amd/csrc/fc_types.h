@@ -335,10 +335,10 @@ namespace fcg
 
     struct QueueCounters  // device-resident, zeroed per bounce
     {
-        uint32_t hit[Q_COUNT];
-        uint32_t ray[2];     // ping-pong: extension rays of this / the next bounce
-        uint32_t shadow;
-        uint32_t pad[4];
+        // every append counter on its own 128-byte line: atomics on one line are served one after the other
+        uint32_t hit[Q_COUNT][32];
+        uint32_t ray[2][32];     // [parity][0]: ping-pong: extension rays of this / the next bounce
+        uint32_t shadow[32];     // [0]
         // dynamic work cursors of the two traversal kernels: one per ray-queue range, each on its own
         // 128-byte line (a single word serves only ~88 atomics/us)
         uint32_t work_extend[WORK_RANGES][32];
