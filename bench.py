@@ -2,7 +2,7 @@
 """Headline benchmark: room scene, Forward MIS, 1920x1080 (BASELINE.json configs[1]).
 
 A "step" renders `--spp-per-step` samples per pixel of the full frame through the HIP wavefront
-path (generate -> {extend, sort, shade<lobe>, shadow} x 10 -> accumulate), in batches of 2^25 paths
+path (generate -> {extend, sort, shade<lobe>, shadow} x 10 -> accumulate), in batches of up to 2^27 paths
 (16 spp); the default 16 steps x 64 spp are the whole 1024-spp job. All inputs (scene, BVH, queues) are resident in HBM before the
 timed region starts; the film stays on the device (read-back is outside the timed region for
 N = 1, the RCCL film reduce is inside it for N > 1).

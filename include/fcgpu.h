@@ -231,7 +231,7 @@ typedef struct fcgpu_options {
     int32_t sort_materials;     /* 1 = material-sorted shade queues (default), 0 = single queue */
     double epsilon;             /* ray-origin offset (scene.hpp:182 uses 1e-6); <=0 selects the default:
                                    1e-6 in f64, 1e-4 in f32 (1e-6 is below fp32 resolution at |p|~16) */
-    uint32_t max_paths_in_flight; /* 0 = default (2^25); a pass is split into batches of at most this */
+    uint32_t max_paths_in_flight; /* 0 = default (2^27); a pass is split into batches of at most this */
     uint32_t bvh_builder;       /* FCGPU_BVH_* */
 } fcgpu_options;
 

@@ -31,9 +31,10 @@ namespace
 
     // Paths per batch. Every kernel of a bounce ends with a tail in which the slowest rays drain while
     // most of the chip idles (~70 us at 1080p whatever the batch size), so batches are made large:
-    // 2^25 paths = 16 samples of a 1080p frame, ~7 GB of queues in fp32 (288 GB of HBM per GPU).
-    // Measured on MI355X: 2^21 -> 199, 2^23 -> 262, 2^25 -> 288 Msamples/s (same kernels).
-    constexpr uint32_t DEFAULT_PATHS_IN_FLIGHT = 1u << 25;
+    // 2^27 paths = 64 samples of a 1080p frame, ~27 GB of queues in fp32 and twice that in fp64 (288 GB of HBM per
+    // GPU); queues are only ever as large as the largest pass asked for. Measured on MI355X: 2^21 -> 199, 2^23 -> 262,
+    // 2^25 -> 288 Msamples/s with the first kernels; 2^24 -> 408, 2^25 -> 436, 2^26 -> 449, 2^27 -> 454 with the last.
+    constexpr uint32_t DEFAULT_PATHS_IN_FLIGHT = 1u << 27;
 }
 
 struct fcgpu_ctx
