@@ -43,7 +43,7 @@ def test_struct_sizes_equal_what_the_c_compiler_sees(tmp_path):
     pairs = [("fcgpu_surface", A.Surface), ("fcgpu_material", A.Material), ("fcgpu_texture", A.Texture), ("fcgpu_medium", A.Medium),
              ("fcgpu_entity", A.Entity), ("fcgpu_camera", A.Camera), ("fcgpu_image", A.Image), ("fcgpu_env_texture", A.EnvTexture),
              ("fcgpu_scene_desc", A.SceneDesc), ("fcgpu_options", A.Options), ("fcgpu_tile", A.Tile), ("fcgpu_ray", A.Ray),
-             ("fcgpu_hit", A.Hit), ("fcgpu_counters", A.Counters), ("fcgpu_stage_times", A.StageTimes)]
+             ("fcgpu_hit", A.Hit), ("fcgpu_counters", A.Counters), ("fcgpu_stage_times", A.StageTimes), ("fcgpu_scene_stats", A.SceneStats)]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "fcgpu.h"\nint main(void){' +
                    "".join(f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) + "return 0;}\n")
