@@ -73,6 +73,7 @@ struct fcgpu_ctx
     size_t timeline_words{};
     int lds_pad_extend{0}, lds_pad_shadow{0};  // FCGPU_LDS_PAD_EXTEND / _SHADOW (bytes)
     int finish_min{16}, descend_min{12};  // traversal tuning, overridable through FCGPU_FINISH_MIN / FCGPU_DESCEND_MIN
+    int finish_min_shadow{16}, descend_min_shadow{24};  // ... FCGPU_FINISH_MIN_SHADOW / FCGPU_DESCEND_MIN_SHADOW
     // stage profiling: a pool of event pairs drained at sync points
     bool profiling{};
     struct TimedSpan
@@ -384,6 +385,8 @@ namespace
         B.film = c->film;
         B.finish_min = c->finish_min;
         B.descend_min = c->descend_min;
+        B.finish_min_shadow = c->finish_min_shadow;
+        B.descend_min_shadow = c->descend_min_shadow;
 
         auto run_one = [&](uint32_t pix0, uint32_t npix, uint32_t s0, uint32_t nsamp)
         {
@@ -634,6 +637,8 @@ extern "C"
         if(const char* e = std::getenv("FCGPU_LDS_PAD_SHADOW")) c->lds_pad_shadow = std::max(0, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_FINISH_MIN")) c->finish_min = std::max(1, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_DESCEND_MIN")) c->descend_min = std::max(0, std::atoi(e));
+        if(const char* e = std::getenv("FCGPU_FINISH_MIN_SHADOW")) c->finish_min_shadow = std::max(1, std::atoi(e));
+        if(const char* e = std::getenv("FCGPU_DESCEND_MIN_SHADOW")) c->descend_min_shadow = std::max(0, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_GRID_MULT")) c->grid = std::max(1, prop.multiProcessorCount) * std::max(1, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_STREAMS")) c->slots = std::atoi(e) >= 2 ? 2 : 1;
         if(c->slots > 1)

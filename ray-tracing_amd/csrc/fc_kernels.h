@@ -24,6 +24,7 @@ namespace fcg
         int32_t W;                   // film width
         int32_t finish_min;          // traversal tuning (see fc_traverse.h / k_extend)
         int32_t descend_min;
+        int32_t finish_min_shadow, descend_min_shadow;  // the same two for k_shadow
         double* film;
     };
 

@@ -999,7 +999,7 @@ namespace fcg
         {
             const bool finished = slot != INVALID_U32 && trav_done(T);
             const bool traversing = slot != INVALID_U32 && !trav_done(T);
-            if(__popcll(__ballot(finished)) >= B.finish_min || __ballot(traversing) == 0ull)
+            if(__popcll(__ballot(finished)) >= B.finish_min_shadow || __ballot(traversing) == 0ull)
             {
                 if(finished)
                 {
@@ -1030,7 +1030,7 @@ namespace fcg
                 }
                 if(__ballot(slot != INVALID_U32) == 0ull) break;
             }
-            trav_round<R, true, BLOCK, SPILL>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims);
+            trav_round<R, true, BLOCK, SPILL>(S, T, stack, nodebuf, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
         }
         wave_stat_add(Q.stats, ST_SHADOW, n_cast);
         wave_stat_add(Q.stats, ST_OCCLUDED, n_occ);
