@@ -1075,6 +1075,7 @@ namespace fcg
         wave_stat_add(Q.stats, ST_NAN, n_nan);
     }
 
+#ifndef FCG_ONLY_F64
     __global__ void k_reset_counters(QueueCounters* c, int parity_to_keep)
     {
         if(threadIdx.x < Q_COUNT) c->hit[threadIdx.x][0] = 0;
@@ -1089,6 +1090,7 @@ namespace fcg
             c->work_shadow[threadIdx.x][0] = 0;
         }
     }
+#endif
 
     // ------------------------------------------------------------------ parity hooks
     template<typename R, bool SPILL>
@@ -1207,10 +1209,12 @@ namespace fcg
     {
         hipLaunchKernelGGL(k_accumulate<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
     }
+#ifndef FCG_ONLY_F64
     void launch_reset_counters(const LaunchCfg& L, QueueCounters* c, int parity_to_keep)
     {
         hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(64), 0, L.stream, c, parity_to_keep);
     }
+#endif
     template<typename R> void launch_trace(const LaunchCfg& L, const SceneDev<R>& S, uint64_t n, const fcgpu_ray* rays,
                                            fcgpu_hit* hits, uint8_t* occluded, unsigned long long* stats)
     {
@@ -1228,6 +1232,13 @@ namespace fcg
     template void launch_shadow<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);            \
     template void launch_accumulate<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);        \
     template void launch_trace<R>(const LaunchCfg&, const SceneDev<R>&, uint64_t, const fcgpu_ray*, fcgpu_hit*, uint8_t*, unsigned long long*);
+    // The library compiles this file twice (Makefile): the fp32 product kernels with the compiler's default fused
+    // multiply-adds, the fp64 parity kernels with -ffp-contract=off, so that decisions a rounding can flip (a sign test at
+    // grazing incidence, a zero test on a BSDF value) fall as they do in the reference, which is built without FMA.
+#ifndef FCG_ONLY_F64
     FCG_INSTANTIATE(float)
+#endif
+#ifndef FCG_ONLY_F32
     FCG_INSTANTIATE(double)
+#endif
 }

@@ -88,14 +88,14 @@ def test_radiance_f64_matches_reference(name):
             assert rel.max() <= 1e-9, (tag, rel.max())
             rays = z[tag + "_rays"]
             assert c.closest_rays == int(rays[0])
-            # visibility rays are cast where bsdf->evaluate() is non-zero: where the light direction lies in the
-            # surface (a vertex on a plane emitter sampling that same emitter: normals_scene has 600 of them) or
-            # grazes it, the sign of dot(n, w) is decided by rounding (device fma contraction), so some rays exist
-            # on one side only -- every one of them occluded, none carrying radiance: the number of UNOCCLUDED
-            # rays, the ones that add to the film, has to agree
+            # visibility rays are cast where bsdf->evaluate() is non-zero, a test that rounding decides where the light
+            # direction lies in the surface (a vertex on a plane emitter sampling that same emitter: normals_scene has
+            # 600 of them) or grazes it. The fp64 kernels are compiled without fused multiply-adds, like the reference
+            # build, so nearly all of these decisions fall the same way (with contraction normals_mirror was 23 rays
+            # off, now 0); what is left, at most 5 rays in 175 000 on these fixtures, is the device's libm against glibc
+            assert abs(int(c.shadow_rays) - int(rays[1])) <= 8
             unoccluded, ref_unoccluded = int(c.shadow_rays) - int(c.shadow_occluded), int(rays[1]) - int(rays[2])
             assert abs(unoccluded - ref_unoccluded) <= 8
-            assert abs(int(c.shadow_rays) - int(rays[1])) <= max(8, 0.05 * int(rays[1]))
             assert c.nan_samples == int(rays[3]) and c.stack_overflows == 0
 
 
@@ -222,7 +222,7 @@ def test_random_scenes_f64_match_the_restatement(seed):
             assert m == n and c.stack_overflows == 0
             assert pixel_rel_err(rgb, ref).max() <= 1e-9, (seed, integ)
             assert c.closest_rays == st.closest_rays and c.nan_samples == st.nan_samples
-            assert abs(int(c.shadow_rays) - int(st.any_rays)) <= max(8, 1e-3 * st.any_rays)
+            assert abs(int(c.shadow_rays) - int(st.any_rays)) <= 8
 
 
 @pytest.mark.parametrize("seed", range(12, 18))
@@ -239,3 +239,4 @@ def test_random_scenes_stratified_on_a_device_built_bvh(seed):
     assert m == n and c.stack_overflows == 0
     assert pixel_rel_err(rgb, ref).max() <= 1e-9
     assert c.closest_rays == st.closest_rays and c.nan_samples == st.nan_samples
+    assert abs(int(c.shadow_rays) - int(st.any_rays)) <= 8
