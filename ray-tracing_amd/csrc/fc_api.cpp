@@ -153,6 +153,7 @@ namespace
     {
         int rc;
         if((rc = upload(c, c->scene_allocs, T.xprims, &S.xprims))) return rc;
+        if((rc = upload(c, c->scene_allocs, T.tri_shade, &S.tri_shade))) return rc;
         if((rc = upload(c, c->scene_allocs, T.lobes, &S.lobes))) return rc;
         if((rc = upload(c, c->scene_allocs, T.media, &S.media))) return rc;
         if((rc = upload(c, c->scene_allocs, T.lights, &S.lights))) return rc;

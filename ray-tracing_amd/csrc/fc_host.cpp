@@ -786,6 +786,40 @@ namespace fcg
             return n;
         }
 
+        // TriShade records in arithmetic R, with the expressions make_surface_point used per hit (mesh_surface.hpp:211-248)
+        template<typename R>
+        void make_tri_shade(const std::vector<TriRec>& tris, const std::vector<TriAttr>& attrs, std::vector<TriShade<R>>& dst)
+        {
+            dst.resize(tris.size());
+            for(size_t k = 0; k < tris.size(); ++k)
+            {
+                const TriRec& T = tris[k];
+                vec3<R> p0{R(T.v0[0]), R(T.v0[1]), R(T.v0[2])}, p1{R(T.v1[0]), R(T.v1[1]), R(T.v1[2])}, p2{R(T.v2[0]), R(T.v2[1]), R(T.v2[2])};
+                vec3<R> dp02 = p0 - p2, dp12 = p1 - p2;
+                vec3<R> ng = normalize(cross(dp02, dp12));
+                vec3<R> dpdu;
+                if(T.attr == INVALID_U32 || T.attr >= attrs.size())  // (the placeholder record of a scene without triangles has attr 0)
+                {
+                    // default uvs (0,0),(1,0),(1,1) (:348-351): det = 1, dpdu = dp12 - dp02
+                    dpdu = (R(-1) * dp02 - R(-1) * dp12) / R(1);
+                }
+                else
+                {
+                    const TriAttr& A = attrs[T.attr];
+                    R d02x = R(A.uv0[0]) - R(A.uv2[0]), d02y = R(A.uv0[1]) - R(A.uv2[1]);
+                    R d12x = R(A.uv1[0]) - R(A.uv2[0]), d12y = R(A.uv1[1]) - R(A.uv2[1]);
+                    R det = d02x * d12y - d02y * d12x;
+                    dpdu = (d12y * dp02 - d02y * dp12) / det;
+                }
+                vec3<R> t = normalize(dpdu);
+                TriShade<R>& o = dst[k];
+                o.ng[0] = ng.x; o.ng[1] = ng.y; o.ng[2] = ng.z;
+                o.t[0] = t.x; o.t[1] = t.y; o.t[2] = t.z;
+                o.entity = T.entity & ENTITY_MASK;
+                o.attr = T.attr;
+            }
+        }
+
         template<typename R>
         void convert_lobes(const std::vector<LobeD>& src, std::vector<LobeRec<R>>& dst)
         {
@@ -1472,6 +1506,8 @@ namespace fcg
         }
         out.tri_attrs = std::move(attrs);
         if(out.tris.empty()) out.tris.push_back(TriRec{});
+        make_tri_shade(out.tris, out.tri_attrs, out.f32.tri_shade);
+        make_tri_shade(out.tris, out.tri_attrs, out.f64.tri_shade);
         if(out.tri_attrs.empty()) out.tri_attrs.push_back(TriAttr{});
 
         std::vector<BoxF> order_box(bin.order.size());

@@ -30,6 +30,7 @@ namespace fcg
     struct FlatTyped  // arrays whose element type depends on the arithmetic type
     {
         std::vector<XPrim<R>> xprims;
+        std::vector<TriShade<R>> tri_shade;  // by triangle index, same order as FlatScene::tris
         std::vector<LobeRec<R>> lobes;
         std::vector<MatParam<R>> matparams;
         std::vector<MediumRec<R>> media;

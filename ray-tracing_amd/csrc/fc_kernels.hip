@@ -590,33 +590,18 @@ namespace fcg
         sp.kind_index = (kind << 30) | idx;
         if(kind == KIND_TRI)
         {
-            // mesh_surface.hpp:211-248
-            const TriRec T = S.tris[idx];
-            sp.entity = T.entity & ENTITY_MASK;
-            vec3<R> p0 = ldv<R>(T.v0), p1 = ldv<R>(T.v1), p2 = ldv<R>(T.v2);
-            vec3<R> dp02 = p0 - p2, dp12 = p1 - p2;
-            sp.f.ng = normalize(cross(dp02, dp12));
-            vec3<R> dpdu;
-            if(T.attr == INVALID_U32)
-            {
-                sp.f.ns = sp.f.ng;
-                // default uvs (0,0),(1,0),(1,1) (:348-351): det = 1, dpdu = dp12 - dp02
-                dpdu = (R(-1) * dp02 - R(-1) * dp12) / R(1);
-            }
-            else
+            // mesh_surface.hpp:211-248; normal and tangent are constants of the triangle, computed at upload (TriShade)
+            const TriShade<R> T = S.tri_shade[idx];
+            sp.entity = T.entity;
+            sp.f.ng = vec3<R>{T.ng[0], T.ng[1], T.ng[2]};
+            sp.f.ns = sp.f.ng;
+            if(T.attr != INVALID_U32 && (S.entities[sp.entity].flags & 1u))
             {
                 const TriAttr& A = S.tri_attrs[T.attr];
                 R b2 = R(1) - b0 - b1;
-                R d02x = R(A.uv0[0]) - R(A.uv2[0]), d02y = R(A.uv0[1]) - R(A.uv2[1]);
-                R d12x = R(A.uv1[0]) - R(A.uv2[0]), d12y = R(A.uv1[1]) - R(A.uv2[1]);
-                R det = d02x * d12y - d02y * d12x;
-                dpdu = (d12y * dp02 - d02y * dp12) / det;
-                if(S.entities[sp.entity].flags & 1u)
-                    sp.f.ns = normalize(b0 * ldv<R>(A.n0) + b1 * ldv<R>(A.n1) + b2 * ldv<R>(A.n2));
-                else
-                    sp.f.ns = sp.f.ng;
+                sp.f.ns = normalize(b0 * ldv<R>(A.n0) + b1 * ldv<R>(A.n1) + b2 * ldv<R>(A.n2));
             }
-            vec3<R> tangent = normalize(dpdu);
+            const vec3<R> tangent{T.t[0], T.t[1], T.t[2]};
             sp.f.b = cross(tangent, sp.f.ns);
             sp.f.t = cross(sp.f.ns, sp.f.b);
         }

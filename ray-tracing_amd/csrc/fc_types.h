@@ -62,6 +62,20 @@ namespace fcg
     static_assert(sizeof(TriRec) == 48, "TriRec is 3 x 16 B");
     constexpr uint32_t ENTITY_MASK = 0x00FFFFFFu, KEY_HINT_NONE = 0xFFu;
 
+    // What shading needs of a triangle, by triangle index, computed once at upload in the arithmetic of the kernels that
+    // read it: geometric normal and tangent (mesh_surface.hpp:212-213, 221-248 are constants of the triangle). 32 bytes in
+    // fp32, so a record never straddles a 128-byte line (a 48-byte TriRec does 3 times in 8) and k_shade neither fetches
+    // the vertices a second time nor normalises twice per hit.
+    template<typename R>
+    struct alignas(16) TriShade
+    {
+        R ng[3];
+        uint32_t entity;  // entity index (no key hint)
+        R t[3];           // normalize(dpdu)
+        uint32_t attr;    // as TriRec::attr
+    };
+    static_assert(sizeof(TriShade<float>) == 32 && sizeof(TriShade<double>) == 64, "TriShade is two 16-byte (32-byte) pieces");
+
     struct TriAttr  // per-triangle vertex attributes, only for meshes that carry them
     {
         float n0[3], n1[3], n2[3];  // world-space vertex normals (mesh_surface.hpp:30-38)
@@ -222,6 +236,7 @@ namespace fcg
         const MediumRec<R>* media;
         const LightRec<R>* lights;
         const double* light_cdf;
+        const TriShade<R>* tri_shade;  // by triangle index
         uint32_t* stack_spill;     // [depth - STACK_CAP][grid lanes] or nullptr when the BVH fits the LDS stack
         uint32_t stack_spill_stride;
         uint32_t textured_materials;  // 1 = some material has image textures (selects the TEX kernel instantiations)

@@ -109,3 +109,12 @@ def test_threaded_bvh_build_gives_the_sequential_tree(monkeypatch):
         st = R.check_scene(sc, "host")
         stats.append((st.primitives, st.binary_nodes, st.wide_nodes, st.max_stack))
     assert stats[0] == stats[1] == stats[2] and stats[0][0] == sc.primitive_total()
+
+
+def test_every_scene_builder_flattens_on_the_host():
+    """All stand-in scenes go through validation, the BVH build and the per-triangle shading records without a device
+    (scenes with a single mesh-less placeholder triangle record included)."""
+    for name, build in S.BUILDERS.items():
+        sc = S.random_scene(1, 32, 24) if name == "random_scene" else build(width=32, height=24)
+        st = R.check_scene(sc)
+        assert st.primitives == sc.primitive_total(), name
