@@ -29,7 +29,7 @@ EXTEND_BYTES_PER_RAY = 48.0     # the extend kernel's own share of it (ray recor
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 (vector)
 # Fabric traffic of k_extend per ray, from the rocprofv3 PMC passes kept under profiles/
-# (r01_pmc_v13_tcc_*.txt: TCC_EA0_RDREQ all 128-byte requests, TCC_EA0_WRREQ split 64/32 bytes; this is
+# (r01_pmc_v14_tcc_*.txt: TCC_EA0_RDREQ all 128-byte requests, TCC_EA0_WRREQ split 64/32 bytes; this is
 # what FETCH_SIZE doubled + WRITE_SIZE give on gfx950): (1.12e8*128 + 2.07e8*64 + 1.60e8*32) B over
 # 3.52e8 rays (123 B/ray before the queue columns went to streaming accesses). Counted at the L2's memory side, i.e. Infinity-Cache hits included.
 EXTEND_TRAFFIC_BYTES_PER_RAY = 87.0
@@ -193,8 +193,8 @@ def main():
                 "kernel": "k_extend<float>" if args.precision == "f32" else "k_extend<double>", "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": EXTEND_TRAFFIC_BYTES_PER_RAY * rays_per_launch if args.precision == "f32" else None,
-                "traffic_note": "bytes per launch = 87 B/ray (PMC, profiles/r01_pmc_v13_tcc_*.txt) x rays per launch; the kernel is "
-                                "VALU/latency bound (VALU busy 85 %, TA busy 78 %, lane utilisation 0.57: profiles/r01_pmc_v13_sq.txt), not HBM bound",
+                "traffic_note": "bytes per launch = 87 B/ray (PMC, profiles/r01_pmc_v14_tcc_*.txt) x rays per launch; the kernel is "
+                                "VALU/latency bound (VALU busy 85 %, TA busy 78 %, lane utilisation 0.57: profiles/r01_pmc_v14_sq.txt), not HBM bound",
                 "avg_launch_us": avg_s * 1e6, "launches": int(launches), "rays_per_launch": rays_per_launch,
                 "algorithmic_bytes_per_ray": EXTEND_BYTES_PER_RAY,
                 "stage_ms": {k: v[0] for k, v in stages.items()},
@@ -208,7 +208,7 @@ def main():
             "primitive_tests_per_ray": int(c.reserved[4]) / local_rays,
             "achieved": rays / elapsed * flops_per_ray / 1e12, "peak": VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
             "frac": rays / elapsed * flops_per_ray / 1e12 / (VALU_PEAK_TFLOPS * world),
-            "pmc": "k_extend: VALU busy 85 % of cycles at lane utilisation 0.57; k_shade: VALU busy 44 %, TA busy 72 % (profiles/r01_pmc_v13_sq.txt)",
+            "pmc": "k_extend: VALU busy 85 % of cycles at lane utilisation 0.57; k_shade: VALU busy 41 %, TA busy 71 % (profiles/r01_pmc_v14_sq.txt)",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref_rgb, tile, ref_nan = cpu_baseline(S, A, args)
