@@ -63,8 +63,8 @@ typedef struct fcgpu_surface {
     uint32_t index_count;     /* multiple of 3; indices are relative to vertex_offset            */
 } fcgpu_surface;
 
-/* materials: the classes under src/materials/ with constant textures (const_texture_2d_*); image
- * textures on material parameters and normal maps are the next row. */
+/* materials: the classes under src/materials/; every parameter is a constant (const_texture_2d_*) or, through the
+ * tex_* handles below, an image / checker texture; tex_normal puts the lobes inside normal_mapping<T>. */
 #define FCGPU_MATERIAL_DIFFUSE 0       /* diffuse_material.hpp:18-38       color_a = reflectance               */
 #define FCGPU_MATERIAL_MIRROR 1        /* mirror_material.hpp:20-56        color_a = reflectance, roughness     */
 #define FCGPU_MATERIAL_GLASS 2         /* glass_material.hpp:19-41         color_a = reflectance, color_b = transmittance, roughness */
@@ -226,13 +226,27 @@ typedef struct fcgpu_scene_desc {
 #define FCGPU_BVH_DEVICE_LBVH 1
 #define FCGPU_BVH_HOST_REFERENCE 2
 
+/* entity_scene::raycast / visibility lift a ray's origin `epsilon` off its surface along the geometric normal
+ * (scene.hpp:85-93, 118-131, 146-152). NORMAL does exactly that. ALONG_RAY advances the origin along the ray until
+ * it is `epsilon` above the surface (capped at 100 epsilon at grazing angles, the rest along the normal): the ray stays
+ * on the reference's line however large epsilon has to be, which is what fp32 needs (its epsilon is 1e-4).
+ * DEFAULT: NORMAL in F64 (the reference's arithmetic), ALONG_RAY in F32. */
+#define FCGPU_OFFSET_DEFAULT 0
+#define FCGPU_OFFSET_NORMAL 1
+#define FCGPU_OFFSET_ALONG_RAY 2
+
 typedef struct fcgpu_options {
     int32_t precision;          /* FCGPU_PRECISION_* */
-    int32_t sort_materials;     /* 1 = material-sorted shade queues (default), 0 = single queue */
+    int32_t sort_materials;     /* must be 1: material-sorted shade queues (one kernel instantiation per lobe type);
+                                   anything else is refused with FCGPU_E_UNSUPPORTED */
     double epsilon;             /* ray-origin offset (scene.hpp:182 uses 1e-6); <=0 selects the default:
                                    1e-6 in f64, 1e-4 in f32 (1e-6 is below fp32 resolution at |p|~16) */
-    uint32_t max_paths_in_flight; /* 0 = default (2^27); a pass is split into batches of at most this */
+    uint32_t max_paths_in_flight; /* 0 = default (2^27); a pass is split into batches of at most this. When the device
+                                   cannot hold the queues of a batch, the batch size is halved (down to 2^16) before
+                                   FCGPU_E_NOMEM is returned */
     uint32_t bvh_builder;       /* FCGPU_BVH_* */
+    uint32_t origin_offset;     /* FCGPU_OFFSET_*: how a ray's origin leaves the surface it starts on */
+    uint32_t reserved;
 } fcgpu_options;
 
 typedef struct fcgpu_tile {
@@ -318,6 +332,16 @@ int fcgpu_render_pass(fcgpu_ctx* ctx, const fcgpu_tile* tile, uint32_t sample_be
                       uint32_t sample_count, int integrator, int max_path_length,
                       int visible_infinity_area_light);
 
+/* Tile sharding over N GPUs (BASELINE config 5; the reference's analogue is its N workers pulling pixels from one
+ * counter, renderer.hpp:65-81, 154-179): the film's rows are cut into bands of `band_rows` rows, i.e. full-width tiles,
+ * and this call renders the bands b with b % band_stride == band_first for every sample index of the range, as ONE
+ * pass (large batches) however many bands that is. With band_first = rank and band_stride = world size every pixel
+ * has exactly one owner, so the summed films (fcgpu_reduce_film, or an RCCL reduce over fcgpu_film_device_ptr) are
+ * bit-identical to a single GPU's. Otherwise like fcgpu_render_pass. */
+int fcgpu_render_bands(fcgpu_ctx* ctx, uint32_t band_rows, uint32_t band_first, uint32_t band_stride,
+                       uint32_t sample_begin, uint32_t sample_count, int integrator, int max_path_length,
+                       int visible_infinity_area_light);
+
 /* Parity hooks. Replace acceleration_structure::raycast_surface_point / raycast
  * (acceleration_structure.hpp:38-39; bvh_acceleration_structure.hpp:31-91, 93-138).
  * Host pointers; synchronous.                                                                */
@@ -331,6 +355,27 @@ int fcgpu_trace_closest_device(fcgpu_ctx* ctx, uint64_t n, const fcgpu_ray* rays
 int fcgpu_trace_any_device(fcgpu_ctx* ctx, uint64_t n, const fcgpu_ray* rays_dev,
                            uint8_t* occluded_dev);
 
+/* Parity hook for the BSDF layer: what `material::evaluate(p) -> bsdf` followed by bsdf::sample_bxdf(u_lobe),
+ * bsdf::evaluate(wo, wi), bsdf::pdf_wi(wo, wi) and bsdf::sample_wi(wo, u1, u2) return (core/bsdf.hpp:46-100, 131-141 over
+ * core/bxdf.hpp:57-127 and the lobe classes of src/bsdfs/) at a surface point with the given frame, computed ON THE
+ * DEVICE by the functions the shade kernels call, in the context's precision. `material`: constants only (no
+ * texture handles). ng / tangent / ns / bitangent: the surface point's geometric normal and shading frame
+ * (surface_point.hpp:48-62). Host pointers; synchronous. Needs no uploaded scene. */
+typedef struct fcgpu_bsdf_query {
+    double wo[3], wi[3];
+    double u_lobe;              /* sample_bxdf draw */
+    double u1[2], u2[2];        /* sample_wi draws */
+} fcgpu_bsdf_query;
+typedef struct fcgpu_bsdf_result {
+    double f[3];                /* evaluate */
+    double pdf;                 /* pdf_wi */
+    double s_wi[3], s_value[3], s_pdf;  /* sample_wi outputs, zero when it failed */
+    int32_t lobe, is_delta, s_ok, reserved;
+} fcgpu_bsdf_result;
+int fcgpu_bsdf_table(fcgpu_ctx* ctx, const fcgpu_material* material, const double* ng, const double* tangent,
+                     const double* ns, const double* bitangent, double eta_a, double eta_b, uint64_t n,
+                     const fcgpu_bsdf_query* queries, fcgpu_bsdf_result* results);
+
 /* Film. Replaces render_target (render_target.hpp:15-23, 30-38) and the sum/count that
  * renderer::export_image divides (renderer.hpp:118-135): rgb_sum[(y*W + x)*3 + c] / sample_count
  * is the pixel value the reference writes. Synchronous.                                      */
@@ -341,6 +386,14 @@ int fcgpu_read_film(fcgpu_ctx* ctx, double* rgb_sum, uint64_t* sample_count);
  * (the analogue of the per-worker film sum, renderer.hpp:129-133).                           */
 int fcgpu_film_device_ptr(fcgpu_ctx* ctx, void** rgb_dev, uint64_t* bytes);
 int fcgpu_add_sample_count(fcgpu_ctx* ctx, int64_t delta);
+/* Replaces the per-worker film sum of renderer::export_image (renderer.hpp:125-135) for one process that drives
+ * several GPUs (one context per device): adds the films and sample counts of all `count` contexts into
+ * ctxs[root] (peer copies over xGMI into a staging film on the root's device + one add kernel each; no host
+ * round trip), then clears the other films and zeroes their sample counts, so that rendering more and reducing again
+ * accumulates. All contexts must hold scenes of the same resolution. Synchronous; the caller must not be rendering
+ * on any of the contexts from another thread. With disjoint pixel ownership (fcgpu_render_bands) the adds are
+ * additions of zero: the result is bit-identical to one GPU's film. Errors are reported on ctxs[root]. */
+int fcgpu_reduce_film(fcgpu_ctx* const* ctxs, int count, int root);
 
 int fcgpu_get_counters(fcgpu_ctx* ctx, fcgpu_counters* out);
 int fcgpu_reset_counters(fcgpu_ctx* ctx);

@@ -30,7 +30,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FCGPU_SAMPLER_FN static inline __host__ __device__
 #else
 #define FCGPU_SAMPLER_FN static inline

@@ -433,6 +433,7 @@ namespace fco
         V3<R> env{};
         EnvTexture<R> envtex{};  // texture_infinity_area_light when envtex.on
         R epsilon{R(0.000001)};  // scene.hpp:182
+        bool offset_along_ray{false};  // fp32 device mode (include/fcgpu.h FCGPU_OFFSET_ALONG_RAY); false = the reference's offset
         Medium<R> vacuum{};      // helper::dummy_medium_, integrator.hpp:115
 
         explicit Scene(const fcgpu_scene_desc& d)
@@ -1682,14 +1683,22 @@ namespace fco
             log->push_back(r);
         }
 
+        // origin offset of scene.hpp:85-93, 118-131, 146-152: epsilon along the geometric normal, to the side `positive` names.
+        // offset_along_ray restates what the fp32 DEVICE does instead (csrc/fc_kernels.hip: lift_origin): advance along the
+        // unit direction w until epsilon above the surface, at most 100 epsilon, the rest along the normal.
+        V3<R> lift(V3<R> p, V3<R> n, V3<R> w, bool positive) const
+        {
+            if(!S.offset_along_ray) return positive ? p + n * S.epsilon : p - n * S.epsilon;
+            const R c = std::abs(dot(n, w));
+            const R a = std::min(S.epsilon / c, R(100) * S.epsilon);
+            const R rest = S.epsilon - a * c;
+            const V3<R> q = p + w * a;
+            return positive ? q + n * rest : q - n * rest;
+        }
         // entity_scene::raycast, scene.hpp:81-108
         bool scene_raycast(const Point<R>& p, V3<R> w, Point<R>& out)
         {
-            V3<R> o = p.position;
-            if(dot(p.normal, w) > R(0))
-                o = o + p.normal * S.epsilon;
-            else
-                o = o - p.normal * S.epsilon;
+            V3<R> o = lift(p.position, p.normal, w, dot(p.normal, w) > R(0));
             uint32_t prim = ~0u;
             R t;
             closest_rays += 1;
@@ -1702,8 +1711,9 @@ namespace fco
         {
             V3<R> p0 = a.position, p1 = b.position, n0 = a.normal, n1 = b.normal;
             V3<R> to1 = p1 - p0;
-            p0 = dot(to1, n0) > R(0) ? p0 + n0 * S.epsilon : p0 - n0 * S.epsilon;
-            p1 = dot(to1, n1) < R(0) ? p1 + n1 * S.epsilon : p1 - n1 * S.epsilon;
+            const V3<R> w01 = S.offset_along_ray ? to1 / length(to1) : to1;  // the direction only matters in the device mode
+            p0 = lift(p0, n0, w01, dot(to1, n0) > R(0));
+            p1 = lift(p1, n1, w01 * R(-1), dot(to1, n1) < R(0));
             to1 = p1 - p0;
             R len = length(to1);
             V3<R> w = to1 / len;
@@ -1716,7 +1726,7 @@ namespace fco
         // entity_scene::visibility(p, w), scene.hpp:144-157
         bool visibility_dir(const Point<R>& p, V3<R> w)
         {
-            V3<R> o = dot(p.normal, w) > R(0) ? p.position + p.normal * S.epsilon : p.position - p.normal * S.epsilon;
+            V3<R> o = lift(p.position, p.normal, w, dot(p.normal, w) > R(0));
             any_rays += 1;
             bool occ = S.any(o, w, std::numeric_limits<R>::infinity(), brute);
             if(occ) any_occluded += 1;
@@ -2216,6 +2226,7 @@ namespace fco
     extern "C" void* PREFIX##_scene_create(const fcgpu_scene_desc* d) { return fco::scene_create<R>(d); }                                          \
     extern "C" void PREFIX##_scene_destroy(void* h) { delete static_cast<fco::Handle<R>*>(h); }                                                    \
     extern "C" void PREFIX##_set_epsilon(void* h, double e) { static_cast<fco::Handle<R>*>(h)->scene->epsilon = static_cast<R>(e); }               \
+    extern "C" void PREFIX##_set_offset_along_ray(void* h, int on) { static_cast<fco::Handle<R>*>(h)->scene->offset_along_ray = on != 0; }         \
     extern "C" void PREFIX##_set_stratified(uint32_t count) { fco::g_stratified_count = count; }                                                  \
     extern "C" int PREFIX##_render(void* h, int integ, int mpl, int vis, uint64_t seed, uint32_t sb, uint32_t sc, int x0, int y0, int w, int hh,     \
                                    int threads, double* rgb, uint64_t* cnt, fco::Stats* st, fco::RayRecord* log, uint64_t cap, uint64_t* nlog)       \

@@ -51,18 +51,19 @@ def _load(path, prefix):
 class _Backend:
     """Common driver for the two CPU checkers (same C entry points, different prefix)."""
 
-    def __init__(self, path, prefix, default_epsilon=None):
+    def __init__(self, path, prefix, default_epsilon=None, along_ray=False):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.lib = _load(path, prefix)
         self.prefix = prefix
         self.default_epsilon = default_epsilon
+        self.along_ray = along_ray  # origin offset of the fp32 device (FCGPU_OFFSET_ALONG_RAY) instead of the reference's
 
     def _fn(self, name):
         return getattr(self.lib, self.prefix + name)
 
-    def scene(self, scene, epsilon=None):
-        return _Scene(self, scene, epsilon)
+    def scene(self, scene, epsilon=None, along_ray=None):
+        return _Scene(self, scene, epsilon, self.along_ray if along_ray is None else along_ray)
 
     def bsdf_table(self, material, queries, ng=(0, 1, 0), tangent=(1, 0, 0), ns=(0, 1, 0), bitangent=(0, 0, 1),
                    eta_a=1.0, eta_b=1.0):
@@ -77,7 +78,7 @@ class _Backend:
 
 
 class _Scene:
-    def __init__(self, backend, scene, epsilon=None):
+    def __init__(self, backend, scene, epsilon=None, along_ray=False):
         self.b = backend
         self.scene = scene
         self.desc = scene.desc()
@@ -92,6 +93,11 @@ class _Scene:
             f.argtypes = [C.c_void_p, C.c_double]
             f.restype = None
             f(self.h, float(epsilon))
+        if along_ray:
+            f = backend._fn("_set_offset_along_ray")  # restatement only: the reference has no such mode
+            f.argtypes = [C.c_void_p, C.c_int]
+            f.restype = None
+            f(self.h, 1)
         self.width, self.height = scene.camera.width, scene.camera.height
 
     def close(self):
@@ -167,7 +173,8 @@ def have_reference():
 
 def restatement(precision="f64"):
     """The independent CPU restatement (oracle/liboracle.so); precision 'f64' or 'f32'."""
-    return _Backend(os.path.join(_HERE, "liboracle.so"), "fcoracle_" + precision, 1e-4 if precision == "f32" else 1e-6)
+    f32 = precision == "f32"  # the float instantiation mirrors the fp32 device: epsilon 1e-4, origins offset along the ray
+    return _Backend(os.path.join(_HERE, "liboracle.so"), "fcoracle_" + precision, 1e-4 if f32 else 1e-6, along_ray=f32)
 
 
 def image_from_film(rgb_sum, count):

@@ -15,6 +15,7 @@ TEXTURE_IMAGE, TEXTURE_CHECKER = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 INTEGRATOR_BSDF, INTEGRATOR_MIS = 0, 1
 BVH_HOST_SAH, BVH_DEVICE_LBVH, BVH_HOST_REFERENCE = 0, 1, 2
+OFFSET_DEFAULT, OFFSET_NORMAL, OFFSET_ALONG_RAY = 0, 1, 2
 
 E_INVALID, E_HIP, E_NOSCENE, E_LIMIT, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
@@ -100,6 +101,7 @@ class Options(C.Structure):
     _fields_ = [
         ("precision", C.c_int32), ("sort_materials", C.c_int32), ("epsilon", C.c_double),
         ("max_paths_in_flight", C.c_uint32), ("bvh_builder", C.c_uint32),
+        ("origin_offset", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -125,6 +127,15 @@ class Counters(C.Structure):
     ]
 
 
+class BsdfQuery(C.Structure):
+    _fields_ = [("wo", c_double3), ("wi", c_double3), ("u_lobe", C.c_double), ("u1", c_double2), ("u2", c_double2)]
+
+
+class BsdfResult(C.Structure):
+    _fields_ = [("f", c_double3), ("pdf", C.c_double), ("s_wi", c_double3), ("s_value", c_double3), ("s_pdf", C.c_double),
+                ("lobe", C.c_int32), ("is_delta", C.c_int32), ("s_ok", C.c_int32), ("reserved", C.c_int32)]
+
+
 class SceneStats(C.Structure):
     _fields_ = [("primitives", C.c_uint64), ("triangles", C.c_uint64), ("binary_nodes", C.c_uint64), ("wide_nodes", C.c_uint64),
                 ("max_stack", C.c_uint64), ("lobe_mask", C.c_uint64), ("reserved", C.c_uint64 * 2)]
@@ -141,7 +152,11 @@ import numpy as _np
 
 ray_dtype = _np.dtype([("origin", "<f8", 3), ("direction", "<f8", 3), ("t_max", "<f8")])
 hit_dtype = _np.dtype([("t", "<f8"), ("b0", "<f8"), ("b1", "<f8"), ("prim", "<u4"), ("reserved", "<u4")])
+bsdf_query_dtype = _np.dtype([("wo", "<f8", 3), ("wi", "<f8", 3), ("u_lobe", "<f8"), ("u1", "<f8", 2), ("u2", "<f8", 2)])
+bsdf_result_dtype = _np.dtype([("f", "<f8", 3), ("pdf", "<f8"), ("s_wi", "<f8", 3), ("s_value", "<f8", 3), ("s_pdf", "<f8"),
+                               ("lobe", "<i4"), ("is_delta", "<i4"), ("s_ok", "<i4"), ("reserved", "<i4")])
 assert ray_dtype.itemsize == C.sizeof(Ray) and hit_dtype.itemsize == C.sizeof(Hit)
+assert bsdf_query_dtype.itemsize == C.sizeof(BsdfQuery) and bsdf_result_dtype.itemsize == C.sizeof(BsdfResult)
 
 # every symbol include/fcgpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -150,5 +165,5 @@ EXPORTS = [
     "fcgpu_trace_closest_device", "fcgpu_trace_any_device", "fcgpu_clear_film", "fcgpu_read_film",
     "fcgpu_film_device_ptr", "fcgpu_add_sample_count", "fcgpu_get_counters", "fcgpu_reset_counters",
     "fcgpu_sync", "fcgpu_set_profiling", "fcgpu_get_stage_times", "fcgpu_stream", "fcgpu_export_image", "fcgpu_version",
-    "fcgpu_check_scene",
+    "fcgpu_check_scene", "fcgpu_render_bands", "fcgpu_reduce_film", "fcgpu_bsdf_table",
 ]

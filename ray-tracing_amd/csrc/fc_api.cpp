@@ -54,6 +54,7 @@ struct fcgpu_ctx
     Wavefront<float> q32{}, q32b{};    // b: second batch slot (two batches in flight, FCGPU_STREAMS=2)
     Wavefront<double> q64{}, q64b{};
     int slots{1};
+    size_t stack_spill_words{};        // words of one batch slot's spill area
     uint32_t* stack_spill{};           // scene_allocs entry: traversal stack entries beyond STACK_CAP, per grid lane
     hipStream_t stream_b{};
     hipStream_t span_stream{};         // stream the next StageSpan records on
@@ -62,6 +63,7 @@ struct fcgpu_ctx
     int queue_precision{-1};
     uint32_t queue_capacity{};
     uint32_t queue_limit{};
+    bool queue_shrunk{};               // the last allocation had to halve the batch size (device memory)
     double* film{};
     uint64_t film_elems{};
     QueueCounters* counters{};
@@ -95,7 +97,8 @@ namespace
 
     int hip_fail(fcgpu_ctx* c, hipError_t e, const char* what)
     {
-        return fail(c, FCGPU_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        if(e == hipErrorOutOfMemory) (void)hipGetLastError();  // the sticky "last error" must not fail the next launch check
+        return fail(c, e == hipErrorOutOfMemory ? FCGPU_E_NOMEM : FCGPU_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
     }
 
     // No C++ exception crosses the ABI (include/fcgpu.h): the entry points that allocate host memory run inside this.
@@ -232,6 +235,7 @@ namespace
     {
         if(c->spans_busy.empty()) return;
         (void)hipStreamSynchronize(c->stream);
+        if(c->stream_b) (void)hipStreamSynchronize(c->stream_b);
         for(auto& s : c->spans_busy)
         {
             float ms = 0.0f;
@@ -274,6 +278,12 @@ namespace
             c->spans_busy.push_back(s);
         }
     };
+
+    bool offset_along_ray(const fcgpu_ctx* c)
+    {
+        if(c->opt.origin_offset == FCGPU_OFFSET_DEFAULT) return c->opt.precision == FCGPU_PRECISION_F32;
+        return c->opt.origin_offset == FCGPU_OFFSET_ALONG_RAY;
+    }
 
     double effective_epsilon(const fcgpu_ctx* c)
     {
@@ -328,23 +338,35 @@ namespace
         return FCGPU_OK;
     }
 
-    // Queues are sized to what the pass needs (at most the configured cap) and only ever grow.
+    // Queues are sized to what the pass needs (at most the configured cap) and only ever grow. When the device cannot
+    // hold them (other tenants, fp64 at the default cap: ~57 GB) the batch size is halved down to 2^16 paths before
+    // FCGPU_E_NOMEM is returned: smaller batches cost speed (longer tails), never correctness.
     int ensure_queues(fcgpu_ctx* c, uint64_t paths_in_pass)
     {
         const uint32_t limit = c->opt.max_paths_in_flight ? c->opt.max_paths_in_flight : DEFAULT_PATHS_IN_FLIGHT;
         if(c->slots > 1) paths_in_pass = (paths_in_pass + 1) / 2;  // two batches in flight share the pass
         uint32_t cap = static_cast<uint32_t>(std::min<uint64_t>(limit, std::max<uint64_t>(paths_in_pass, 256)));
-        if(c->queue_precision == c->opt.precision && c->queue_limit == limit && c->queue_capacity >= cap) return FCGPU_OK;
+        if(c->queue_precision == c->opt.precision && c->queue_limit == limit && (c->queue_capacity >= cap || c->queue_shrunk)) return FCGPU_OK;
         c->queue_limit = limit;
+        c->queue_shrunk = false;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if(c->stream_b) HIP_TRY(c, hipStreamSynchronize(c->stream_b));
         free_pool(c->queue_allocs);
         c->queue_precision = -1;
-        int rc = c->opt.precision == FCGPU_PRECISION_F64 ? alloc_wavefront(c, c->q64, cap) : alloc_wavefront(c, c->q32, cap);
-        if(!rc && c->slots > 1)
+        int rc;
+        for(;;)
         {
-            rc = c->opt.precision == FCGPU_PRECISION_F64 ? alloc_wavefront(c, c->q64b, cap) : alloc_wavefront(c, c->q32b, cap);
-            c->q64b.counters = c->counters_b;
-            c->q32b.counters = c->counters_b;
+            rc = c->opt.precision == FCGPU_PRECISION_F64 ? alloc_wavefront(c, c->q64, cap) : alloc_wavefront(c, c->q32, cap);
+            if(!rc && c->slots > 1)
+            {
+                rc = c->opt.precision == FCGPU_PRECISION_F64 ? alloc_wavefront(c, c->q64b, cap) : alloc_wavefront(c, c->q32b, cap);
+                c->q64b.counters = c->counters_b;
+                c->q32b.counters = c->counters_b;
+            }
+            if(rc != FCGPU_E_NOMEM || cap <= (1u << 16)) break;
+            free_pool(c->queue_allocs);
+            cap = std::max(cap / 2, 1u << 16);
+            c->queue_shrunk = true;  // the device is full: later passes reuse these queues instead of asking for more
         }
         if(rc)
         {
@@ -356,11 +378,19 @@ namespace
         return FCGPU_OK;
     }
 
+    // Rows of a pass dealt in bands (fcgpu_render_bands): band b of `rows` film rows belongs to this pass when
+    // b % stride == first. rows == 0: a plain tile.
+    struct Bands
+    {
+        uint32_t rows{0}, first{0}, stride{1};
+    };
+
     template<typename R>
-    int run_batches(fcgpu_ctx* c, SceneDev<R> S, const Wavefront<R>& Qa, const Wavefront<R>& Qb, const fcgpu_tile& tile,
+    int run_batches(fcgpu_ctx* c, SceneDev<R> S, const Wavefront<R>& Qa, const Wavefront<R>& Qb, const fcgpu_tile& tile, const Bands& bands,
                     uint32_t sample_begin, uint32_t sample_count, int integrator, int max_len, int visible_env)
     {
         S.epsilon = static_cast<R>(effective_epsilon(c));
+        S.offset_along_ray = offset_along_ray(c) ? 1u : 0u;
         const uint64_t P = static_cast<uint64_t>(tile.w) * static_cast<uint64_t>(tile.h);
         const uint64_t cap = Qa.capacity;
         // Two batch slots (FCGPU_STREAMS=2): consecutive batches run on two streams with their own queues,
@@ -378,6 +408,8 @@ namespace
         B.y0 = tile.y0;
         B.tw = tile.w;
         B.div_tw = make_fastdiv(static_cast<uint32_t>(tile.w));
+        B.div_band = make_fastdiv(bands.rows ? bands.rows : 1u);
+        B.band_skip = bands.rows ? (bands.stride - 1u) * bands.rows : 0u;
         B.sampler = c->sampler;
         B.max_len = max_len;
         B.integrator = integrator;
@@ -395,6 +427,8 @@ namespace
             const Wavefront<R>& Q = slot ? Qb : Qa;
             LaunchCfg L{slot ? c->stream_b : c->stream, c->grid, c->lds_pad_extend, c->lds_pad_shadow};
             c->span_stream = L.stream;
+            // two batches in flight traverse at the same time: each slot has its own spill columns
+            if(c->stack_spill) S.stack_spill = c->stack_spill + static_cast<size_t>(slot) * c->stack_spill_words;
             B.pix0 = pix0;
             B.npix = npix;
             B.div_npix = make_fastdiv(npix);
@@ -547,11 +581,27 @@ namespace
             return FCGPU_OK;
         });
     }
+    // shared tail of fcgpu_render_pass / fcgpu_render_bands: `tile` is validated by the caller (with bands: x0 = 0, full
+    // width, y0 = first owned row, h = number of owned rows)
+    int render_rows(fcgpu_ctx* c, const fcgpu_tile& tile, const Bands& bands, uint32_t sample_begin, uint32_t sample_count, int integrator,
+                    int max_path_length, int visible_env)
+    {
+        if(integrator != FCGPU_INTEGRATOR_BSDF && integrator != FCGPU_INTEGRATOR_MIS) return fail(c, FCGPU_E_INVALID, "unknown integrator");
+        if(max_path_length < 1 || max_path_length > 1000) return fail(c, FCGPU_E_INVALID, "max_path_length out of range");
+        if(static_cast<uint64_t>(sample_begin) + sample_count > (1u << 24)) return fail(c, FCGPU_E_LIMIT, "sample index >= 2^24");
+        if(sample_count == 0) return FCGPU_OK;
+        HIP_TRY(c, hipSetDevice(c->device));
+        int rc = ensure_queues(c, static_cast<uint64_t>(tile.w) * static_cast<uint64_t>(tile.h) * sample_count);
+        if(rc) return rc;
+        if(c->opt.precision == FCGPU_PRECISION_F64)
+            return run_batches(c, c->s64, c->q64, c->q64b, tile, bands, sample_begin, sample_count, integrator, max_path_length, visible_env);
+        return run_batches(c, c->s32, c->q32, c->q32b, tile, bands, sample_begin, sample_count, integrator, max_path_length, visible_env);
+    }
 }
 
 extern "C"
 {
-    int fcgpu_version(void) { return 1002; }
+    int fcgpu_version(void) { return 1003; }
 
     int fcgpu_check_scene(const fcgpu_scene_desc* d, uint32_t bvh_builder, fcgpu_scene_stats* out)
     {
@@ -704,6 +754,8 @@ extern "C"
             if(opt->precision != FCGPU_PRECISION_F32 && opt->precision != FCGPU_PRECISION_F64) return fail(c, FCGPU_E_INVALID, "unknown precision");
             if(opt->max_paths_in_flight != 0 && opt->max_paths_in_flight < 256) return fail(c, FCGPU_E_INVALID, "max_paths_in_flight < 256");
             if(opt->bvh_builder > FCGPU_BVH_HOST_REFERENCE) return fail(c, FCGPU_E_INVALID, "unknown bvh_builder");
+            if(opt->origin_offset > FCGPU_OFFSET_ALONG_RAY) return fail(c, FCGPU_E_INVALID, "unknown origin_offset");
+            if(opt->sort_materials != 1) return fail(c, FCGPU_E_UNSUPPORTED, "sort_materials must be 1: the shade kernels are one instantiation per lobe type");
             c->opt = *opt;
             return FCGPU_OK;
         });
@@ -750,13 +802,18 @@ extern "C"
             c->flat = std::move(flat);
 
             c->stack_spill = nullptr;
-            if(c->flat.max_stack > static_cast<uint32_t>(STACK_CAP))
+            c->stack_spill_words = 0;
+            // The kernels without spill code stop pushing once fewer than three free LDS entries are left (one test per
+            // node step instead of one per push), which is exact only while the worst case is <= STACK_CAP - 2: any
+            // deeper hierarchy, including the ones that would just fit, runs the SPILL instantiations.
+            if(c->flat.max_stack > static_cast<uint32_t>(STACK_CAP - 2))
             {
                 // deep BVH: the part of the worst-case stack beyond the LDS entries lives in global memory,
-                // one column per lane of the persistent grid
+                // one column per lane of the persistent grid (and per batch slot)
                 void* p = nullptr;
-                const size_t entries = c->flat.max_stack - static_cast<uint32_t>(STACK_CAP);
-                HIP_TRY(c, hipMalloc(&p, entries * static_cast<size_t>(c->grid) * 256u * sizeof(uint32_t)));
+                const size_t entries = c->flat.max_stack > static_cast<uint32_t>(STACK_CAP) ? c->flat.max_stack - static_cast<uint32_t>(STACK_CAP) : 1u;
+                c->stack_spill_words = entries * static_cast<size_t>(c->grid) * 256u;
+                HIP_TRY(c, hipMalloc(&p, c->stack_spill_words * sizeof(uint32_t) * static_cast<size_t>(c->slots)));
                 c->scene_allocs.push_back(p);
                 c->stack_spill = static_cast<uint32_t*>(p);
             }
@@ -802,16 +859,27 @@ extern "C"
             if(!tile) tile = &full;
             if(tile->w <= 0 || tile->h <= 0 || tile->x0 < 0 || tile->y0 < 0 || tile->x0 + tile->w > c->flat.width || tile->y0 + tile->h > c->flat.height)
                 return fail(c, FCGPU_E_INVALID, "tile outside the film");
-            if(integrator != FCGPU_INTEGRATOR_BSDF && integrator != FCGPU_INTEGRATOR_MIS) return fail(c, FCGPU_E_INVALID, "unknown integrator");
-            if(max_path_length < 1 || max_path_length > 1000) return fail(c, FCGPU_E_INVALID, "max_path_length out of range");
-            if(static_cast<uint64_t>(sample_begin) + sample_count > (1u << 24)) return fail(c, FCGPU_E_LIMIT, "sample index >= 2^24");
-            if(sample_count == 0) return FCGPU_OK;
-            HIP_TRY(c, hipSetDevice(c->device));
-            int rc = ensure_queues(c, static_cast<uint64_t>(tile->w) * static_cast<uint64_t>(tile->h) * sample_count);
-            if(rc) return rc;
-            if(c->opt.precision == FCGPU_PRECISION_F64)
-                return run_batches(c, c->s64, c->q64, c->q64b, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
-            return run_batches(c, c->s32, c->q32, c->q32b, *tile, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
+            return render_rows(c, *tile, Bands{}, sample_begin, sample_count, integrator, max_path_length, visible_infinity_area_light);
+        });
+    }
+
+    int fcgpu_render_bands(fcgpu_ctx* c, uint32_t band_rows, uint32_t band_first, uint32_t band_stride, uint32_t sample_begin,
+                           uint32_t sample_count, int integrator, int max_path_length, int visible_infinity_area_light)
+    {
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+            if(band_rows == 0 || band_stride == 0 || band_first >= band_stride || band_rows > (1u << 20) || band_stride > (1u << 20))
+                return fail(c, FCGPU_E_INVALID, "band_rows and band_stride must be positive, band_first < band_stride");
+            // rows this context owns: band b = y / band_rows with b % band_stride == band_first, packed in order
+            const uint64_t H = static_cast<uint64_t>(c->flat.height);
+            uint64_t owned = 0;
+            for(uint64_t y0 = static_cast<uint64_t>(band_first) * band_rows; y0 < H; y0 += static_cast<uint64_t>(band_stride) * band_rows)
+                owned += std::min<uint64_t>(band_rows, H - y0);
+            if(owned == 0) return FCGPU_OK;  // more GPUs than bands: nothing to do here
+            const fcgpu_tile rows{0, static_cast<int32_t>(band_first * band_rows), c->flat.width, static_cast<int32_t>(owned)};
+            return render_rows(c, rows, Bands{band_rows, band_first, band_stride}, sample_begin, sample_count, integrator, max_path_length,
+                               visible_infinity_area_light);
         });
     }
 
@@ -834,6 +902,119 @@ extern "C"
     {
         if(c && !occluded_dev && n) return fail(c, FCGPU_E_INVALID, "null output");
         return trace_device(c, n, rays_dev, nullptr, occluded_dev);
+    }
+
+    // ------------------------------------------------------------------ multi-GPU film reduce (renderer.hpp:125-135)
+    int fcgpu_reduce_film(fcgpu_ctx* const* ctxs, int count, int root)
+    {
+        fcgpu_ctx* r = (ctxs && count > 0 && root >= 0 && root < count) ? ctxs[root] : nullptr;
+        return guarded(r, [&]() -> int {
+            if(!r) return FCGPU_E_INVALID;
+            for(int i = 0; i < count; ++i)
+            {
+                if(!ctxs[i]) return fail(r, FCGPU_E_INVALID, "null context in the list");
+                if(!ctxs[i]->has_scene) return fail(r, FCGPU_E_NOSCENE, "a context has no scene");
+                if(ctxs[i]->film_elems != r->film_elems || ctxs[i]->flat.width != r->flat.width) return fail(r, FCGPU_E_INVALID, "films differ in resolution");
+                for(int j = 0; j < i; ++j)
+                    if(ctxs[j] == ctxs[i]) return fail(r, FCGPU_E_INVALID, "a context is listed twice");
+            }
+            if(count == 1) return FCGPU_OK;
+            const size_t bytes = sizeof(double) * r->film_elems;
+            // every contributor has finished rendering before its film is read
+            for(int i = 0; i < count; ++i)
+            {
+                HIP_TRY(r, hipSetDevice(ctxs[i]->device));
+                HIP_TRY(r, hipStreamSynchronize(ctxs[i]->stream));
+                if(ctxs[i]->stream_b) HIP_TRY(r, hipStreamSynchronize(ctxs[i]->stream_b));
+            }
+            HIP_TRY(r, hipSetDevice(r->device));
+            void* staging = nullptr;  // one film on the root's device: the landing zone of the peer copies (xGMI between GPUs)
+            HIP_TRY(r, hipMalloc(&staging, bytes));
+            int rc = FCGPU_OK;
+            for(int i = 0; i < count && rc == FCGPU_OK; ++i)
+            {
+                if(i == root) continue;
+                fcgpu_ctx* s = ctxs[i];
+                hipError_t e = s->device == r->device ? hipMemcpyAsync(staging, s->film, bytes, hipMemcpyDeviceToDevice, r->stream)
+                                                      : hipMemcpyPeerAsync(staging, r->device, s->film, s->device, bytes, r->stream);
+                if(e != hipSuccess)
+                {
+                    rc = hip_fail(r, e, "film peer copy");
+                    break;
+                }
+                launch_film_add(LaunchCfg{r->stream, r->grid}, r->film, static_cast<const double*>(staging), r->film_elems);
+                if((e = hipStreamSynchronize(r->stream)) != hipSuccess)
+                {
+                    rc = hip_fail(r, e, "film add");
+                    break;
+                }
+                // the contributor starts over: a later render + reduce adds only what is new
+                r->samples += s->samples;
+                s->samples = 0;
+                if((e = hipSetDevice(s->device)) != hipSuccess || (e = hipMemsetAsync(s->film, 0, bytes, s->stream)) != hipSuccess ||
+                   (e = hipStreamSynchronize(s->stream)) != hipSuccess)
+                    rc = hip_fail(r, e, "film clear");
+                (void)hipSetDevice(r->device);
+            }
+            (void)hipFree(staging);
+            return rc;
+        });
+    }
+
+    // ------------------------------------------------------------------ per-lobe parity hook
+    int fcgpu_bsdf_table(fcgpu_ctx* c, const fcgpu_material* material, const double* ng, const double* tangent, const double* ns,
+                         const double* bitangent, double eta_a, double eta_b, uint64_t n, const fcgpu_bsdf_query* queries,
+                         fcgpu_bsdf_result* results)
+    {
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!material || !ng || !tangent || !ns || !bitangent) return fail(c, FCGPU_E_INVALID, "null argument");
+            if(n == 0) return FCGPU_OK;
+            if(!queries || !results) return fail(c, FCGPU_E_INVALID, "null buffer");
+            if(material->tex_color_a || material->tex_color_b || material->tex_roughness || material->tex_metalness || material->tex_ior || material->tex_normal)
+                return fail(c, FCGPU_E_UNSUPPORTED, "fcgpu_bsdf_table takes constant materials (no texture handles)");
+            std::vector<LobeRec<float>> l32;
+            std::vector<LobeRec<double>> l64;
+            std::string err;
+            const int lobes = material_lobe_table(*material, l32, l64, err);
+            if(lobes <= 0) return fail(c, lobes < 0 ? lobes : FCGPU_E_INVALID, lobes < 0 ? err : "material without lobes");
+            HIP_TRY(c, hipSetDevice(c->device));
+            std::vector<void*> pool;
+            struct Free
+            {
+                std::vector<void*>& p;
+                ~Free() { free_pool(p); }
+            } on_exit{pool};
+            const bool f64 = c->opt.precision == FCGPU_PRECISION_F64;
+            void *d_lobes = nullptr, *d_q = nullptr, *d_out = nullptr;
+            const size_t lobe_bytes = f64 ? sizeof(LobeRec<double>) * l64.size() : sizeof(LobeRec<float>) * l32.size();
+            HIP_TRY(c, hipMalloc(&d_lobes, lobe_bytes));
+            pool.push_back(d_lobes);
+            HIP_TRY(c, hipMalloc(&d_q, sizeof(fcgpu_bsdf_query) * n));
+            pool.push_back(d_q);
+            HIP_TRY(c, hipMalloc(&d_out, sizeof(fcgpu_bsdf_result) * n));
+            pool.push_back(d_out);
+            HIP_TRY(c, hipMemcpyAsync(d_lobes, f64 ? static_cast<const void*>(l64.data()) : static_cast<const void*>(l32.data()), lobe_bytes, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(d_q, queries, sizeof(fcgpu_bsdf_query) * n, hipMemcpyHostToDevice, c->stream));
+            double frame[12];
+            for(int k = 0; k < 3; ++k)
+            {
+                frame[k] = ng[k];
+                frame[3 + k] = tangent[k];
+                frame[6 + k] = ns[k];
+                frame[9 + k] = bitangent[k];
+            }
+            const LaunchCfg L{c->stream, c->grid};
+            if(f64)
+                launch_bsdf_table<double>(L, static_cast<const LobeRec<double>*>(d_lobes), lobes, frame, eta_a, eta_b, n, static_cast<const fcgpu_bsdf_query*>(d_q), static_cast<fcgpu_bsdf_result*>(d_out));
+            else
+                launch_bsdf_table<float>(L, static_cast<const LobeRec<float>*>(d_lobes), lobes, frame, eta_a, eta_b, n, static_cast<const fcgpu_bsdf_query*>(d_q), static_cast<fcgpu_bsdf_result*>(d_out));
+            hipError_t e = hipGetLastError();
+            if(e != hipSuccess) return hip_fail(c, e, "bsdf table launch");
+            HIP_TRY(c, hipMemcpyAsync(results, d_out, sizeof(fcgpu_bsdf_result) * n, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            return FCGPU_OK;
+        });
     }
 
     int fcgpu_clear_film(fcgpu_ctx* c)
@@ -971,6 +1152,7 @@ extern "C"
             uint64_t count = 0;
             int rc = fcgpu_read_film(c, sum.data(), &count);
             if(rc) return rc;
+            if(count == 0) return fail(c, FCGPU_E_INVALID, "nothing rendered yet: the image would be 0 / 0");
             std::string path = std::string(name) + ".raw";
             FILE* f = std::fopen(path.c_str(), "wb");
             if(!f) return fail(c, FCGPU_E_INVALID, "cannot open " + path);

@@ -5,10 +5,18 @@
 //   bxdf_adapter<T> (side flip, eta swap, eta^2 scaling)      src/core/bxdf.hpp:57-127
 //   bsdf (shading frame, ng/ns consistency, lobe factor)      src/core/bsdf.hpp:62-100,131-141
 // Local shading space is y-up: local = (w.t, w.ns, w.b) (bsdf.hpp:156-172).
-// normal_mapping<T> is taken on its `skip_` path (normal_mapping.hpp:34-35,745-750), which is
-// the only path reachable without a normal-map texture.
+// normal_mapping<T> (normal_mapping.hpp:32-734) around the lambertian / specular / microfacet reflection lobes is the
+// NM = true instantiation below (nm_combine); without a normal-map texture its `skip_` path (:34-35, 745-750) is the
+// bare lobe.
 #pragma once
 #include "fc_types.h"
+
+#ifndef FCG_FP32_FRESNEL
+#define FCG_FP32_FRESNEL 1
+#endif
+#ifndef FCG_FP32_GLASS
+#define FCG_FP32_GLASS 1
+#endif
 
 namespace fcg
 {
@@ -16,10 +24,25 @@ namespace fcg
     template<typename R> FC_HD R fr_dielectric(R cos_i, R eta_i, R eta_t)  // common.hpp:8-20
     {
         cos_i = clampr(cos_i, R(-1), R(1));
-        R sin_i = r_sqrt(r_max(R(0), R(1) - cos_i * cos_i));
-        R sin_t = eta_i / eta_t * sin_i;
-        if(sin_t >= R(1)) return R(1);
-        R cos_t = r_sqrt(r_max(R(0), R(1) - sin_t * sin_t));
+        R cos_t;
+        if constexpr(sizeof(R) == 4 && FCG_FP32_FRESNEL)
+        {
+            // fp32: cos_t^2 = 1 - eta^2 (1 - cos_i^2) regrouped as (1 - eta)(1 + eta) + eta^2 cos_i^2. The reference's
+            // order (via sin_i, sin_t) cancels at grazing incidence between nearly equal indices: in fp32 it returned
+            // F = 7e-4 instead of 0 at cos_i = 1e-3, eta = 1, which value = F / cos turns into 0.56 (tests/test_gpu_parity.py:
+            // device bsdf tables). One square root less as well.
+            const R eta = eta_i / eta_t;
+            const R cos2_t = (R(1) - eta) * (R(1) + eta) + eta * eta * cos_i * cos_i;
+            if(!(cos2_t > R(0))) return R(1);
+            cos_t = r_sqrt(cos2_t);
+        }
+        else
+        {
+            R sin_i = r_sqrt(r_max(R(0), R(1) - cos_i * cos_i));
+            R sin_t = eta_i / eta_t * sin_i;
+            if(sin_t >= R(1)) return R(1);
+            cos_t = r_sqrt(r_max(R(0), R(1) - sin_t * sin_t));
+        }
         R r_parl = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
         R r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
         return (r_parl * r_parl + r_perp * r_perp) / R(2);
@@ -326,13 +349,29 @@ namespace fcg
         else if constexpr(TYPE == L_SPEC_GLASS)  // specular_glass.hpp:25-74
         {
             R cos_i = i.y;
-            R sin2_i = R(1) - cos_i * cos_i;
-            R sin_i = r_sqrt(sin2_i);
             R eta = eta_a / eta_b;
-            R sin_t = eta * sin_i;
-            R cos_t = r_sqrt(R(1) - sin_t * sin_t);
+            R cos_t;
+            bool transmits;
+            if constexpr(sizeof(R) == 4 && FCG_FP32_GLASS)
+            {
+                // fp32: the regrouped cos_t^2 of fr_dielectric (no cancellation at grazing incidence / close indices).
+                // i is not a unit vector where the shading frame is not orthonormal (a rotated sphere: its tangent stays
+                // unrotated, sphere_surface.hpp:130-140); the reference then takes sqrt(1 - cos_i^2) of a negative
+                // number and its NaN fails `sin_t < 1`, i.e. it reflects with F = 1: the second test keeps that.
+                const R cos2_t = (R(1) - eta) * (R(1) + eta) + eta * eta * cos_i * cos_i;
+                transmits = cos2_t > R(0) && cos_i * cos_i <= R(1);
+                cos_t = r_sqrt(r_max(cos2_t, R(0)));
+            }
+            else
+            {
+                R sin2_i = R(1) - cos_i * cos_i;
+                R sin_i = r_sqrt(sin2_i);
+                R sin_t = eta * sin_i;
+                cos_t = r_sqrt(R(1) - sin_t * sin_t);
+                transmits = sin_t < R(1);
+            }
             R F = R(1);
-            if(sin_t < R(1))
+            if(transmits)
             {
                 R r_parl = ((eta_b * cos_i) - (eta_a * cos_t)) / ((eta_b * cos_i) + (eta_a * cos_t));
                 R r_perp = ((eta_a * cos_i) - (eta_b * cos_t)) / ((eta_a * cos_i) + (eta_b * cos_t));

@@ -1085,6 +1085,19 @@ namespace fcg
         }
     }  // namespace
 
+    // The lobes of one constant material exactly as a scene upload precomputes them (fcgpu_bsdf_table parity hook)
+    int material_lobe_table(const fcgpu_material& m, std::vector<LobeRec<float>>& f32, std::vector<LobeRec<double>>& f64, std::string& err)
+    {
+        std::vector<LobeD> lobes;
+        const int n = material_lobes(m, lobes, err);
+        if(n < 0) return n;
+        f32.clear();
+        f64.clear();
+        convert_lobes(lobes, f32);
+        convert_lobes(lobes, f64);
+        return n;
+    }
+
     int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err, const HierarchyBuilder* device_builder, bool reference_split_rule)
     {
         out = FlatScene{};

@@ -77,4 +77,8 @@ namespace fcg
     // `reference_split_rule`: the host builder searches splits exactly as the reference does (FCGPU_BVH_HOST_REFERENCE).
     int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err, const HierarchyBuilder* device_builder = nullptr,
                       bool reference_split_rule = false);
+
+    // Lobes of one constant material (material::evaluate + the bsdf constructor) as an upload precomputes them: double
+    // arithmetic, converted per precision. Returns the lobe count or a negative error code.
+    int material_lobe_table(const fcgpu_material& m, std::vector<LobeRec<float>>& f32, std::vector<LobeRec<double>>& f64, std::string& err);
 }

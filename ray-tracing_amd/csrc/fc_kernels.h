@@ -14,6 +14,10 @@ namespace fcg
         int32_t x0, y0, tw;          // tile origin and width
         uint32_t pix0, npix;         // pixel-in-tile range of this batch
         FastDiv div_npix, div_tw;    // slot -> (sample, pixel) and pixel -> (row, column)
+        // band sharding (fcgpu_render_bands): row r of the pass is film row y0 + r + (r / band_rows) * band_skip, i.e. the
+        // bands of band_rows rows that this GPU owns, packed; band_skip = 0 (and div_band = 1) for a plain tile
+        FastDiv div_band;
+        uint32_t band_skip;
         uint32_t s0, nsamp;          // sample range of this batch; slots = npix * nsamp
         fcgpu_sampler_config sampler;  // include/fcgpu_sampler.h: seed + mode (random / stratified)
         int32_t h;                   // hit index being produced / shaded: 1 = camera ray's hit
@@ -46,6 +50,13 @@ namespace fcg
     template<typename R> void launch_shadow(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);
     template<typename R> void launch_accumulate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B);
     void launch_reset_counters(const LaunchCfg& L, QueueCounters* c, int parity_to_keep);
+
+    // dst[i] += src[i] over the film of the root context (fcgpu_reduce_film)
+    void launch_film_add(const LaunchCfg& L, double* dst, const double* src, uint64_t n);
+    // frame = ng, tangent, ns, bitangent (3 doubles each); device pointers (fcgpu_bsdf_table)
+    template<typename R>
+    void launch_bsdf_table(const LaunchCfg& L, const LobeRec<R>* lobes, int lobe_count, const double* frame, double eta_a, double eta_b, uint64_t n,
+                           const fcgpu_bsdf_query* queries, fcgpu_bsdf_result* results);
 
     template<typename R> void launch_trace(const LaunchCfg& L, const SceneDev<R>& S, uint64_t n, const fcgpu_ray* rays,
                                            fcgpu_hit* hits, uint8_t* occluded, unsigned long long* stats);

@@ -16,6 +16,9 @@
 // No MFMA: nothing here is a dense contraction.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "../../include/fcgpu_sampler.h"
 #include "fc_bsdf.h"
 #include "fc_env.h"
@@ -43,7 +46,7 @@ namespace fcg
         uint32_t pit = B.pix0 + (slot - sl * B.npix);
         uint32_t row = fast_div(pit, B.div_tw);
         px = static_cast<uint32_t>(B.x0) + (pit - row * static_cast<uint32_t>(B.tw));
-        py = static_cast<uint32_t>(B.y0) + row;
+        py = static_cast<uint32_t>(B.y0) + row + fast_div(row, B.div_band) * B.band_skip;  // band_skip = 0 unless rows are dealt in bands
         sample = B.s0 + sl;
     }
 
@@ -160,6 +163,24 @@ namespace fcg
         return (ms & ~7u) | (n + 1);
     }
 
+    // Ray-origin offset of entity_scene::raycast / visibility (scene.hpp:85-93, 118-131, 146-152). The reference lifts the
+    // origin epsilon = 1e-6 off the surface along the geometric normal, to the side the ray leaves on (`positive` =
+    // its test on dot(n, w)). fp32 cannot resolve 1e-6 at scene coordinates, and the 1e-4 it needs, applied along the
+    // normal, moves the whole ray sideways by up to 1e-4: measured at the headline configuration that alone, in fp64
+    // arithmetic, takes 12 % of the pixels more than 1 % away from the reference at 16 spp.
+    // S.offset_along_ray (the fp32 default) therefore advances the origin ALONG THE RAY until it is epsilon above the
+    // surface: the ray stays on the reference's line, only its first epsilon / |cos| are skipped; at grazing angles the
+    // advance is capped at 100 epsilon and the rest of the height comes from the normal as before. w: unit direction of travel.
+    template<typename R> FC_D vec3<R> lift_origin(const SceneDev<R>& S, vec3<R> p, vec3<R> n, vec3<R> w, bool positive)
+    {
+        if(!S.offset_along_ray) return positive ? p + n * S.epsilon : p - n * S.epsilon;
+        const R c = r_abs(dot(n, w));
+        const R a = r_min(S.epsilon / c, R(100) * S.epsilon);
+        const R rest = S.epsilon - a * c;
+        const vec3<R> q = p + w * a;
+        return positive ? q + n * rest : q - n * rest;
+    }
+
     // ------------------------------------------------------------------ generate
     template<typename R>
     __global__ __launch_bounds__(BLOCK) void k_generate(SceneDev<R> S, Wavefront<R> Q, Batch B)
@@ -190,7 +211,7 @@ namespace fcg
             vec3<R> origin = xf_point(C.fwd, lens);
             vec3<R> n_cam{C.fwd[2], C.fwd[6], C.fwd[10]};
             // entity_scene::raycast origin offset, scene.hpp:85-93
-            vec3<R> o = dot(n_cam, wi) > R(0) ? origin + n_cam * S.epsilon : origin - n_cam * S.epsilon;
+            vec3<R> o = lift_origin(S, origin, n_cam, wi, dot(n_cam, wi) > R(0));
 
             PathState<R> st{};
             st.beta[0] = st.beta[1] = st.beta[2] = R(1);  // beta0 = W*H is folded into the film scale
@@ -334,7 +355,7 @@ namespace fcg
                             if(S.media[med].priority <= S.media[top].priority)
                             {
                                 ms = medium_push(ms, med, n_moverflow);  // the re-cast leaves p INTO its medium, :36-44
-                                p = p - nrm * S.epsilon;                 // scene.hpp:86-93 with dot(n, w) <= 0
+                                p = lift_origin(S, p, nrm, dir, false);  // scene.hpp:86-93 with dot(n, w) <= 0
                                 recast = true;
                             }
                             else
@@ -355,7 +376,7 @@ namespace fcg
                                 const uint32_t new_top = medium_top(S, ms);
                                 if(S.media[new_top].priority == S.media[top].priority)
                                 {
-                                    p = p + nrm * S.epsilon;
+                                    p = lift_origin(S, p, nrm, dir, true);
                                     recast = true;
                                 }
                                 else
@@ -824,7 +845,7 @@ namespace fcg
                                     R pdf_l = pdf_light * pdf_wi;
                                     R weight = power_heuristic(pdf_l, pdf_bsdf);
                                     vec3<R> c = (beta * f * Le) * (weight * r_abs(dot(ng, wi)) / pdf_l);  // :68
-                                    vec3<R> o = dot(ng, wi) > R(0) ? sp.p + ng * S.epsilon : sp.p - ng * S.epsilon;  // scene.hpp:144-157
+                                    vec3<R> o = lift_origin(S, sp.p, ng, wi, dot(ng, wi) > R(0));  // scene.hpp:144-157
                                     emit_shadow = true;
                                     s0 = Vec4<R>{o.x, o.y, o.z, wi.x};
                                     s1 = Vec4<R>{wi.y, wi.z, consts<R>::inf, pack_word(R(0), path)};
@@ -853,8 +874,8 @@ namespace fcg
                                 R weight = power_heuristic(pdf_light_pL, pdf_bsdf_pL);
                                 vec3<R> c = (beta * f * G * LeL) * (weight / pdf_light_pL);  // :86-91
                                 // entity_scene::visibility(p0, p1), scene.hpp:110-142
-                                vec3<R> q0 = dot(d1L, ng) > R(0) ? sp.p + ng * S.epsilon : sp.p - ng * S.epsilon;
-                                vec3<R> q1 = dot(d1L, nL) < R(0) ? pL + nL * S.epsilon : pL - nL * S.epsilon;
+                                vec3<R> q0 = lift_origin(S, sp.p, ng, w1L, dot(d1L, ng) > R(0));
+                                vec3<R> q1 = lift_origin(S, pL, nL, -w1L, dot(d1L, nL) < R(0));
                                 vec3<R> to1 = q1 - q0;
                                 R len = length(to1);
                                 vec3<R> w01 = to1 / len;
@@ -889,7 +910,7 @@ namespace fcg
                         uint32_t overflow = 0;
                         if(ent.medium != 0 && dot(wn, ng) <= R(0)) ms = medium_push(ms, static_cast<uint32_t>(ent.medium), overflow);
                         if(overflow) atomicAdd(&Q.stats[ST_MEDIUM_OVERFLOW], 1ull);
-                        vec3<R> o = dot(ng, wn) > R(0) ? sp.p + ng * S.epsilon : sp.p - ng * S.epsilon;
+                        vec3<R> o = lift_origin(S, sp.p, ng, wn, dot(ng, wn) > R(0));
                         emit_ray = true;
                         r0 = Vec4<R>{o.x, o.y, o.z, wn.x};
                         r1 = Vec4<R>{wn.y, wn.z, R(0), R(0)};
@@ -1037,7 +1058,7 @@ namespace fcg
             uint32_t pit = B.pix0 + pp;
             uint32_t row = fast_div(pit, B.div_tw);
             uint32_t px = static_cast<uint32_t>(B.x0) + (pit - row * static_cast<uint32_t>(B.tw));
-            uint32_t py = static_cast<uint32_t>(B.y0) + row;
+            uint32_t py = static_cast<uint32_t>(B.y0) + row + fast_div(row, B.div_band) * B.band_skip;
             double* out = B.film + 3ull * (static_cast<uint64_t>(py) * static_cast<uint64_t>(B.W) + px);
             double r = out[0], g = out[1], b = out[2];
             for(uint32_t sl = 0; sl < B.nsamp; ++sl)
@@ -1128,6 +1149,87 @@ namespace fcg
         wave_stat_add(stats, ST_STACK_SPILL, n_overflow.spilled);
     }
 
+    // ------------------------------------------------------------------ multi-GPU film sum (fcgpu_reduce_film)
+#ifndef FCG_ONLY_F64
+    __global__ __launch_bounds__(BLOCK) void k_film_add(double* dst, const double* src, uint64_t n)
+    {
+        for(uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * BLOCK) dst[i] += src[i];
+    }
+    void launch_film_add(const LaunchCfg& L, double* dst, const double* src, uint64_t n)
+    {
+        hipLaunchKernelGGL(k_film_add, dim3(L.grid), dim3(BLOCK), 0, L.stream, dst, src, n);
+    }
+#endif
+
+    // ------------------------------------------------------------------ per-lobe parity hook (fcgpu_bsdf_table)
+    // One query per thread through the very functions k_extend / k_shade call: the lobe pick of bsdf::sample_bxdf
+    // (bsdf.hpp:46-55), then bsdf::evaluate / pdf_wi / sample_wi (bsdf.hpp:62-100, 131-141) of the picked lobe.
+    template<typename R>
+    __global__ __launch_bounds__(BLOCK) void k_bsdf_table(const LobeRec<R>* lobes, int lobe_count, ShadingFrame<R> frame, R eta_a, R eta_b, uint64_t n,
+                                                          const fcgpu_bsdf_query* queries, fcgpu_bsdf_result* results)
+    {
+        for(uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * BLOCK)
+        {
+            const fcgpu_bsdf_query q = queries[i];
+            int lobe = 0;
+            for(int l = lobe_count - 1; l >= 0; --l)
+            {
+                if(q.u_lobe > lobes[l].cdf)
+                {
+                    lobe = l;
+                    break;
+                }
+            }
+            const LobeRec<R> L = lobes[lobe];
+            const vec3<R> wo{R(q.wo[0]), R(q.wo[1]), R(q.wo[2])}, wi{R(q.wi[0]), R(q.wi[1]), R(q.wi[2])};
+            vec3<R> f{}, s_wi{}, s_value{};
+            R pdf = R(0), s_pdf = R(0);
+            bool ok = false;
+            auto run = [&](auto key) {
+                constexpr int KEY = decltype(key)::value;
+                f = bsdf_evaluate<KEY>(L, frame, wo, wi, eta_a, eta_b);
+                pdf = bsdf_pdf_wi<KEY>(L, frame, wo, wi, eta_a, eta_b);
+                ok = bsdf_sample_wi<KEY>(L, frame, wo, eta_a, eta_b, R(q.u1[0]), R(q.u1[1]), R(q.u2[0]), R(q.u2[1]), s_wi, s_value, s_pdf);
+            };
+            switch(L.type)
+            {
+            case L_LAMBERT: run(std::integral_constant<int, L_LAMBERT>{}); break;
+            case L_GGX_REFL: run(std::integral_constant<int, L_GGX_REFL>{}); break;
+            case L_SPEC_REFL: run(std::integral_constant<int, L_SPEC_REFL>{}); break;
+            case L_GGX_GLASS: run(std::integral_constant<int, L_GGX_GLASS>{}); break;
+            case L_SPEC_GLASS: run(std::integral_constant<int, L_SPEC_GLASS>{}); break;
+            case L_GGX_TRANS: run(std::integral_constant<int, L_GGX_TRANS>{}); break;
+            default: run(std::integral_constant<int, L_SPEC_TRANS>{}); break;
+            }
+            fcgpu_bsdf_result r{};
+            r.lobe = lobe;
+            r.is_delta = lobe_is_delta(L.type) ? 1 : 0;
+            r.f[0] = static_cast<double>(f.x); r.f[1] = static_cast<double>(f.y); r.f[2] = static_cast<double>(f.z);
+            r.pdf = static_cast<double>(pdf);
+            r.s_ok = ok ? 1 : 0;
+            if(ok)
+            {
+                r.s_wi[0] = static_cast<double>(s_wi.x); r.s_wi[1] = static_cast<double>(s_wi.y); r.s_wi[2] = static_cast<double>(s_wi.z);
+                r.s_value[0] = static_cast<double>(s_value.x); r.s_value[1] = static_cast<double>(s_value.y); r.s_value[2] = static_cast<double>(s_value.z);
+                r.s_pdf = static_cast<double>(s_pdf);
+            }
+            results[i] = r;
+        }
+    }
+    template<typename R>
+    void launch_bsdf_table(const LaunchCfg& L, const LobeRec<R>* lobes, int lobe_count, const double* frame, double eta_a, double eta_b, uint64_t n,
+                           const fcgpu_bsdf_query* queries, fcgpu_bsdf_result* results)
+    {
+        auto v = [&](int k) { return vec3<R>{R(frame[3 * k]), R(frame[3 * k + 1]), R(frame[3 * k + 2])}; };
+        ShadingFrame<R> f;
+        f.ng = v(0);
+        f.t = v(1);
+        f.ns = v(2);
+        f.b = v(3);
+        const int grid = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(L.grid), (n + BLOCK - 1) / BLOCK));
+        hipLaunchKernelGGL(k_bsdf_table<R>, dim3(grid), dim3(BLOCK), 0, L.stream, lobes, lobe_count, f, R(eta_a), R(eta_b), n, queries, results);
+    }
+
     // ------------------------------------------------------------------ launchers
     template<typename R> void launch_generate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
@@ -1216,7 +1318,8 @@ namespace fcg
     template void launch_shade<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&, int);        \
     template void launch_shadow<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);            \
     template void launch_accumulate<R>(const LaunchCfg&, const SceneDev<R>&, const Wavefront<R>&, const Batch&);        \
-    template void launch_trace<R>(const LaunchCfg&, const SceneDev<R>&, uint64_t, const fcgpu_ray*, fcgpu_hit*, uint8_t*, unsigned long long*);
+    template void launch_trace<R>(const LaunchCfg&, const SceneDev<R>&, uint64_t, const fcgpu_ray*, fcgpu_hit*, uint8_t*, unsigned long long*); \
+    template void launch_bsdf_table<R>(const LaunchCfg&, const LobeRec<R>*, int, const double*, double, double, uint64_t, const fcgpu_bsdf_query*, fcgpu_bsdf_result*);
     // The library compiles this file twice (Makefile): the fp32 product kernels with the compiler's default fused
     // multiply-adds, the fp64 parity kernels with -ffp-contract=off, so that decisions a rounding can flip (a sign test at
     // grazing incidence, a zero test on a BSDF value) fall as they do in the reference, which is built without FMA.

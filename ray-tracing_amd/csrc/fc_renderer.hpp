@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/fcgpu.h"
+#include "../../include/fcgpu_sampler.h"
 
 namespace fcgpu
 {
@@ -37,6 +38,9 @@ namespace fcgpu
             check(fcgpu_set_options(ctx_, &opt));
             check(fcgpu_upload_scene(ctx_, &scene));
             check(stratified ? fcgpu_set_sampler_stratified(ctx_, seed, sample_count) : fcgpu_set_sampler(ctx_, seed));
+            // renderer::run_pixel loops over sampler.get_sample_count() (renderer.hpp:159), which for stratified_sampler is
+            // floor(sqrt(sample_count))^2 (stratified_sampler.hpp:15-16, 26-29), not the number it was constructed with
+            if(stratified) sample_count_ = fcgpu_sampler_stratified(seed, sample_count).count;
         }
         gpu_renderer(const gpu_renderer&) = delete;
         gpu_renderer& operator=(const gpu_renderer&) = delete;

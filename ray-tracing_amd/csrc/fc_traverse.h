@@ -246,7 +246,9 @@ namespace fcg
         uint32_t next = key[0] != INVALID_U32 ? ch[0] : INVALID_U32;
         if(!SPILL)
         {
-            // the BVH's worst case fits the LDS stack (checked at upload): `room` is always true
+            // one test per step instead of one per push: exact while the BVH's worst case is <= STACK_CAP - 2 entries (a step
+            // that has anything to push then starts at sp <= STACK_CAP - 3); the upload gives every deeper hierarchy,
+            // also one that would just fit, the SPILL instantiation, so `room` is always true here
             const bool room = sp <= STACK_CAP - 3;
             overflow.lost += (!room && key[1] != INVALID_U32) ? 1u : 0u;
 #pragma unroll

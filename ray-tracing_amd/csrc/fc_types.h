@@ -245,6 +245,7 @@ namespace fcg
         int32_t env_kind;
         R env[3];
         R epsilon;
+        uint32_t offset_along_ray;  // 1: origins leave their surface along the ray (fp32 default), 0: along the normal like the reference (lift_origin)
         EnvTex<R> envtex;     // env_kind == FCGPU_ENV_TEXTURE
     };
 

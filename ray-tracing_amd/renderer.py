@@ -6,6 +6,7 @@ the scene, integrator parameters and sampler (seed + sample count), `run()`, the
 gfx950); there is NO CPU fallback: loading fails loudly when the library is missing.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -61,6 +62,9 @@ def load_library():
         "fcgpu_export_image": (i32, [vp, C.c_char_p]),
         "fcgpu_version": (i32, []),
         "fcgpu_check_scene": (i32, [P(A.SceneDesc), u32, P(A.SceneStats)]),
+        "fcgpu_render_bands": (i32, [vp, u32, u32, u32, u32, u32, i32, i32, i32]),
+        "fcgpu_reduce_film": (i32, [P(vp), i32, i32]),
+        "fcgpu_bsdf_table": (i32, [vp, P(A.Material), vp, vp, vp, vp, C.c_double, C.c_double, u64, vp, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -125,12 +129,14 @@ class GpuContext:
     def __exit__(self, *exc):
         self.close()
 
-    def set_options(self, precision="f32", epsilon=0.0, max_paths_in_flight=0, sort_materials=True, bvh_builder="host"):
+    def set_options(self, precision="f32", epsilon=0.0, max_paths_in_flight=0, sort_materials=True, bvh_builder="host",
+                    origin_offset="default"):
         """bvh_builder: "host" = SAH build on the host (three-axis split search), "device" = linear BVH built on the GPU,
         "reference" = host SAH build with the reference's own split search (its tree)."""
         o = A.Options(precision=A.PRECISION_F64 if precision == "f64" else A.PRECISION_F32,
                       sort_materials=int(sort_materials), epsilon=epsilon, max_paths_in_flight=max_paths_in_flight,
-                      bvh_builder={"host": A.BVH_HOST_SAH, "device": A.BVH_DEVICE_LBVH, "reference": A.BVH_HOST_REFERENCE}[bvh_builder])
+                      bvh_builder={"host": A.BVH_HOST_SAH, "device": A.BVH_DEVICE_LBVH, "reference": A.BVH_HOST_REFERENCE}[bvh_builder],
+                      origin_offset={"default": A.OFFSET_DEFAULT, "normal": A.OFFSET_NORMAL, "along_ray": A.OFFSET_ALONG_RAY}[origin_offset])
         self._check(self.lib.fcgpu_set_options(self.h, C.byref(o)))
 
     def upload_scene(self, scene):
@@ -151,6 +157,21 @@ class GpuContext:
         t = A.Tile(*tile) if tile is not None else None
         self._check(self.lib.fcgpu_render_pass(self.h, C.byref(t) if t is not None else None, sample_begin, sample_count,
                                                integrator, max_path_length, int(visible_env)))
+
+    def render_bands(self, band_rows, band_first, band_stride, sample_begin, sample_count, integrator=A.INTEGRATOR_MIS,
+                     max_path_length=10, visible_env=True):
+        """Tile sharding: the bands b of `band_rows` film rows with b % band_stride == band_first, as one pass."""
+        self._check(self.lib.fcgpu_render_bands(self.h, band_rows, band_first, band_stride, sample_begin, sample_count, integrator,
+                                                max_path_length, int(visible_env)))
+
+    def bsdf_table(self, material, queries, ng=(0, 1, 0), tangent=(1, 0, 0), ns=(0, 1, 0), bitangent=(0, 0, 1), eta_a=1.0, eta_b=1.0):
+        """Device-side bsdf evaluate / pdf_wi / sample_wi of a constant material at a surface frame (parity hook)."""
+        q = np.ascontiguousarray(queries, dtype=A.bsdf_query_dtype)
+        out = np.zeros(len(q), dtype=A.bsdf_result_dtype)
+        vecs = [np.ascontiguousarray(v, dtype=np.float64) for v in (ng, tangent, ns, bitangent)]
+        self._check(self.lib.fcgpu_bsdf_table(self.h, C.byref(material), *[v.ctypes.data for v in vecs], eta_a, eta_b, len(q),
+                                              q.ctypes.data, out.ctypes.data))
+        return out
 
     def trace_closest(self, rays):
         rays = np.ascontiguousarray(rays, dtype=A.ray_dtype)
@@ -235,7 +256,9 @@ class GpuRenderer:
         self.integrator = A.INTEGRATOR_MIS if integrator == "mis" else A.INTEGRATOR_BSDF
         self.max_path_length = max_path_length
         self.visible = visible_infinity_area_light
-        self.sample_count = sample_count
+        # renderer::run_pixel renders sampler.get_sample_count() samples (renderer.hpp:159): for stratified_sampler that is
+        # floor(sqrt(sample_count))^2 (stratified_sampler.hpp:15-16, 26-29), not the count it was constructed with
+        self.sample_count = math.isqrt(int(sample_count)) ** 2 if sampler == "stratified" else sample_count
         self.tiles = tiles  # None = whole image; else list of (x0, y0, w, h) owned by this GPU
 
     def run(self, sample_begin=0, sample_count=None):
@@ -256,6 +279,14 @@ class GpuRenderer:
 
     def close(self):
         self.ctx.close()
+
+
+def reduce_film(contexts, root=0):
+    """fcgpu_reduce_film: films and sample counts of all contexts summed into contexts[root] (one process, several GPUs)."""
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    rc = contexts[0].lib.fcgpu_reduce_film(arr, len(contexts), root)
+    if rc != 0:
+        raise FcgpuError(rc, contexts[0].lib.fcgpu_last_error(contexts[root].h if 0 <= root < len(contexts) else None).decode())
 
 
 def shard_tiles(width, height, rank, world, tile=64):

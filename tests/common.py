@@ -36,3 +36,21 @@ def pixel_rel_err(img, ref):
 def film_stratified(z):
     """stratified sample count of a film fixture (None = random stream)"""
     return (int(z["stratified"]) or None) if "stratified" in z.files else None
+
+
+def ribbon_scene(n, g=1.1):
+    """Strip of n quads whose width grows geometrically: the SAH tree is a chain, so the worst-case traversal stack
+    grows with n (tests/test_host_logic.py pins the depths the GPU tests rely on)."""
+    x0 = g ** np.arange(n + 1) - 1.0
+    pos = np.zeros((2 * (n + 1), 3), np.float32)
+    pos[0::2, 0], pos[1::2, 0] = x0, x0
+    pos[1::2, 2] = 1.0
+    pos[:, 1] = 0.25 * pos[:, 0] * np.where(np.arange(2 * (n + 1)) % 2 == 0, 1.0, -1.0)
+    k = np.arange(n, dtype=np.uint32) * 2
+    idx = np.stack([k, k + 1, k + 2, k + 2, k + 1, k + 3], 1).reshape(-1)
+    sc = S.Scene()
+    sc.entity(sc.mesh(pos, idx), sc.diffuse((0.7, 0.7, 0.7)))
+    sc.set_env((1.0, 0.9, 0.8))
+    sc.set_camera((20.0, 6.0, 6.0), (np.radians(40.0), np.radians(180.0), 0.0), np.radians(60.0), 48, 32)
+    return sc
+

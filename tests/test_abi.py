@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(A.EXPORTS)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.fcgpu_version() == 1002
+    assert lib.fcgpu_version() == 1003
 
 
 def test_struct_layouts_match_header():
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(A.Camera) == 9 * 8 + 8
     assert C.sizeof(A.Ray) == 56 and C.sizeof(A.Hit) == 32
     assert C.sizeof(A.Counters) == 16 * 8
-    assert C.sizeof(A.Options) == 24
+    assert C.sizeof(A.Options) == 32
 
 
 def test_struct_sizes_equal_what_the_c_compiler_sees(tmp_path):

@@ -5,16 +5,20 @@ Bars (stated here, repeated in DESIGN.md):
   * fp64 mode: per-pixel radiance within 1e-9 relative of the reference (same algorithm, same
     precision; only libm ulps and FMA contraction differ); closest-hit primitive ids identical on
     the dumped ray sets; ray counts equal up to 1e-3 relative.
-  * fp32 mode (the fast path): closest-hit ids identical except a near-tie fraction <= 1e-3, with
-    |t_gpu - t_ref| <= 1e-4 * max(1, t_ref); per-pixel radiance on identical streams:
-    median relative error <= 1e-4 and >= 90 % of pixels within 1e-2 at 4 spp (individual paths
-    legitimately diverge after a discrete decision flips; those pixels are not bounded), image
-    mean within 2 %.
+  * fp32 mode (the fast path): closest-hit ids identical except a near-tie fraction <= 1e-3, every
+    differing id explained by distance (classify_id_mismatches), |t_gpu - t_ref| <= 1e-4 * max(1, t_ref);
+    per-pixel radiance on identical streams at the fixtures' 2..20 spp: median relative error <= 5e-6 and
+    >= 99 % of pixels within 1e-2 (a path whose discrete decision flips on a rounding legitimately
+    diverges; those pixels are not bounded), image mean within 0.5 %. At the headline configuration
+    (1080p, tess 64, 16 spp) the same bar is tests/test_gpu_headline.py's.
 """
+import ctypes as C
+import os
+
 import numpy as np
 import pytest
 
-from common import A, FILM_FIXTURES, R, RAY_FIXTURES, S, film_stratified, load_film, load_rays, pixel_rel_err
+from common import A, FILM_FIXTURES, GOLDEN, R, RAY_FIXTURES, S, film_stratified, load_film, load_rays, pixel_rel_err
 from oracle import pyref
 
 pytestmark = pytest.mark.gpu
@@ -42,12 +46,33 @@ def test_closest_hit_ids_f64(name):
     assert (anyh != z["any_hit"]).mean() <= 1e-4
 
 
+def classify_id_mismatches(h, ref_prim, ref_t, ray_t_max):
+    """Every closest-hit id that differs from the reference's must be explained by distance: a NEAR-TIE (the two
+    primitives are hit at the same distance within 1e-4 * max(1, t): shared edges, coplanar faces), or, for rays whose
+    ends sit closer to a surface than fp32 resolves (the reference's own rays: 1e-6), an END-SURFACE case: one side
+    reports the surface the ray starts on (t <= 1e-4) or the one it ends on (t within 1e-4 * max(1, t_max) of the ray's
+    t_max: a shadow ray reaching its light) where the other does not see it. Returns (mismatch, near-tie, end-surface)
+    masks; a mismatch in neither class is a traversal or intersector error."""
+    t_gpu = np.where(h["prim"] == 0xFFFFFFFF, np.inf, h["t"])
+    t_ref = np.where(ref_prim == 0xFFFFFFFF, np.inf, ref_t)
+    mismatch = h["prim"] != ref_prim
+    with np.errstate(invalid="ignore"):
+        near_tie = mismatch & (np.abs(t_gpu - t_ref) <= 1e-4 * np.maximum(1.0, np.minimum(t_gpu, t_ref)))
+        t_seen = np.minimum(t_gpu, t_ref)  # the hit only one side reports
+        at_end = np.isfinite(ray_t_max) & (np.abs(t_seen - ray_t_max) <= 1e-4 * np.maximum(1.0, ray_t_max))
+    ends = mismatch & ~near_tie & ((t_seen <= 1e-4) | at_end)
+    return mismatch, near_tie, ends
+
+
 @pytest.mark.parametrize("name", RAY_FIXTURES)
 def test_closest_hit_ids_f32_near_tie_fraction(name):
-    """fp32 device against the reference's answers on (a) uniform random rays and (b) the rays an fp32
-    render casts (origins 1e-4 off the surfaces). The reference's own logged rays start 1e-6 off a
-    surface, which fp32 cannot represent at these coordinates: every one is a near-tie, so for them
-    only a loose bound is asserted."""
+    """fp32 device against the reference's answers (bvh_acceleration_structure.hpp:31-91) on (a) uniform random rays,
+    (b) the rays an fp32 render casts (origins 1e-4 off the surfaces) and (c) the rays the reference itself logged,
+    whose origins sit 1e-6 off a surface: below fp32 resolution at these coordinates, so in fp32 the origin may round
+    onto or through its own surface.
+    Bar (north_star: ids exact except a stated near-tie fraction): on (a) and (b) ids differ on <= 1e-3 of the rays
+    and EVERY differing id is a near-tie in distance; on (c) every differing id is a near-tie or an end-surface case,
+    near-ties <= 1e-3, end-surface cases <= 3e-2 (measured: 1.6e-2 on the room, 7e-4 on the zoo)."""
     z, scene = load_rays(name)
     nrnd = int(z["n_random"])
     with make_ctx(scene, "f32") as ctx:
@@ -57,18 +82,23 @@ def test_closest_hit_ids_f32_near_tie_fraction(name):
         any32 = ctx.trace_any(z["rays32"])
         assert ctx.counters().stack_overflows == 0
 
-    def check(h, ref_prim, ref_t, a, ref_a, bound, label, check_t=True):
-        mismatch = h["prim"] != ref_prim
-        print(f"{name} {label}: prim-id mismatch {mismatch.mean():.2e}, any-hit mismatch {(a != ref_a).mean():.2e}")
-        assert mismatch.mean() <= bound and (a != ref_a).mean() <= bound
+    def check(h, ref_prim, ref_t, a, ref_a, label, start_bound, t_max, check_t=True):
+        mismatch, near_tie, start = classify_id_mismatches(h, ref_prim, ref_t, t_max)
+        unexplained = mismatch & ~near_tie & ~start
+        print(f"{name} {label}: {len(ref_prim)} rays, id mismatches {mismatch.mean():.2e} = near-ties {near_tie.mean():.2e} + "
+              f"end-surface {start.mean():.2e} + unexplained {int(unexplained.sum())}; any-hit mismatch {(a != ref_a).mean():.2e}")
+        assert not unexplained.any(), [(int(i), int(h["prim"][i]), int(ref_prim[i]), float(h["t"][i]), float(ref_t[i])) for i in np.flatnonzero(unexplained)[:8]]
+        assert near_tie.mean() <= 1e-3 and start.mean() <= start_bound
+        assert (a != ref_a).mean() <= max(1e-3, start_bound)
         ok = (~mismatch) & (ref_prim != 0xFFFFFFFF)
         err = np.abs(h["t"][ok] - ref_t[ok]) / np.maximum(1.0, ref_t[ok])
-        if check_t:
+        if check_t:  # (not for the reference's own rays: a start 1e-6 off a curved surface is not representable in fp32)
             assert np.quantile(err, 0.999) <= 1e-4 and err.max() <= 5e-2  # the tail is grazing incidence
 
-    check(hits[-nrnd:], z["bvh_prim"][-nrnd:], z["bvh_t"][-nrnd:], anyh[-nrnd:], z["any_hit"][-nrnd:], 1e-3, "random rays")
-    check(hits32, z["rays32_prim"], z["rays32_t"], any32, z["rays32_any"], 1e-3, "fp32-render rays")
-    check(hits[:-nrnd], z["bvh_prim"][:-nrnd], z["bvh_t"][:-nrnd], anyh[:-nrnd], z["any_hit"][:-nrnd], 3e-2, "reference-logged rays (all near-ties in fp32)", check_t=False)
+    tm = z["rays"]["t_max"]
+    check(hits[-nrnd:], z["bvh_prim"][-nrnd:], z["bvh_t"][-nrnd:], anyh[-nrnd:], z["any_hit"][-nrnd:], "random rays", 0.0, tm[-nrnd:])
+    check(hits32, z["rays32_prim"], z["rays32_t"], any32, z["rays32_any"], "fp32-render rays", 0.0, z["rays32"]["t_max"])
+    check(hits[:-nrnd], z["bvh_prim"][:-nrnd], z["bvh_t"][:-nrnd], anyh[:-nrnd], z["any_hit"][:-nrnd], "reference-logged rays", 3e-2, tm[:-nrnd], check_t=False)
 
 
 @pytest.mark.parametrize("name", FILM_FIXTURES)
@@ -110,9 +140,9 @@ def test_radiance_f32_within_stated_tolerance(name):
     ref = z["mis_rgb_sum"]
     rel = pixel_rel_err(rgb, ref)
     print(f"{name}: fp32 median rel err {np.median(rel):.2e}, within 1e-2: {(rel <= 1e-2).mean():.3f}")
-    assert np.median(rel) <= 1e-4
-    assert (rel <= 1e-2).mean() >= 0.90
-    assert abs(rgb.mean() - ref.mean()) <= 0.02 * ref.mean()
+    assert np.median(rel) <= 5e-6
+    assert (rel <= 1e-2).mean() >= 0.99
+    assert abs(rgb.mean() - ref.mean()) <= 0.005 * ref.mean()
 
 
 def test_f32_matches_f32_restatement_statistically():
@@ -240,3 +270,101 @@ def test_random_scenes_stratified_on_a_device_built_bvh(seed):
     assert pixel_rel_err(rgb, ref).max() <= 1e-9
     assert c.closest_rays == st.closest_rays and c.nan_samples == st.nan_samples
     assert abs(int(c.shadow_rays) - int(st.any_rays)) <= 8
+
+
+# ------------------------------------------------------------------ per-lobe tables on the device (fcgpu_bsdf_table)
+def _bsdf_table_cases():
+    z = np.load(os.path.join(GOLDEN, "bsdf_tables.npz"))
+    names = [str(n) for n in z["material_names"]]
+    stored = np.frombuffer(z["materials"].tobytes(), dtype=np.uint8).reshape(len(names), -1)
+    mats = np.zeros((len(names), C.sizeof(A.Material)), np.uint8)
+    mats[:, : stored.shape[1]] = stored  # the fixture predates the tex_* handles: zero = constant parameter
+    for mi, name in enumerate(names):
+        m = A.Material.from_buffer_copy(mats[mi].tobytes())
+        for ei, (ea, eb) in enumerate(z["etas"]):
+            for fi, fr in enumerate(z["frames"]):
+                yield name, ei, fi, m, float(ea), float(eb), fr, z[f"t|{name}|{ei}|{fi}"], z["queries"]
+
+
+def _singular(ref_rows):
+    """Rows where the reference itself returns rounding noise amplified without bound: the refraction Jacobian
+    -o.h / (eta i.h + o.h)^2 (microfacet_glass.hpp:54, microfacet_transmission.hpp:39) with eta_a == eta_b, whose
+    denominator is exactly zero in exact arithmetic (values of 1e31..inf). Nothing can be compared there."""
+    with np.errstate(invalid="ignore"):
+        return ~np.isfinite(ref_rows).all(axis=1) | (np.abs(ref_rows).max(axis=1) > 1e20)
+
+
+def test_device_bsdf_tables_f64_match_reference():
+    """bsdf::evaluate / pdf_wi / sample_wi of every material class computed by the device functions the shade kernels
+    call, in fp64, against the REAL reference's tables (tests/golden/bsdf_tables.npz: 512 queries incl. grazing
+    directions at |cos| = 1e-3, four eta pairs incl. (1.3614, 1.52) and (1, 1), an orthonormal and a sphere-like skewed
+    frame). Bar: discrete outputs (picked lobe, delta flag, sample success) identical; every real field within 1e-10
+    relative, or 1e-12 of the field's typical magnitude where the exact value is zero (Fresnel between equal indices:
+    the reference returns 1e-31, i.e. its own rounding noise); singular rows (see _singular) must be singular here too."""
+    checked = singular = 0
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision="f64")
+        for name, ei, fi, m, ea, eb, fr, ref, q in _bsdf_table_cases():
+            got = ctx.bsdf_table(m, q, ng=fr[0], tangent=fr[1], ns=fr[2] / np.linalg.norm(fr[2]), bitangent=fr[3], eta_a=ea, eta_b=eb)
+            for field in ("lobe", "is_delta", "s_ok"):
+                assert np.array_equal(got[field], ref[field]), (name, ei, fi, field)
+            for field in ("f", "pdf", "s_wi", "s_value", "s_pdf"):
+                a, b = got[field].reshape(len(q), -1), ref[field].reshape(len(q), -1)
+                sing = _singular(b)
+                singular += int(sing.sum())
+                with np.errstate(invalid="ignore"):
+                    assert (~np.isfinite(a[sing]).all(axis=1) | (np.abs(a[sing]).max(axis=1) > 1e20)).all(), (name, ei, fi, field)
+                scale = np.median(np.abs(b[~sing][np.abs(b[~sing]) > 1e-20])) if (np.abs(b[~sing]) > 1e-20).any() else 0.0
+                assert np.allclose(a[~sing], b[~sing], rtol=1e-10, atol=1e-12 * scale), (name, ei, fi, field)
+            checked += len(q)
+    assert checked == 12 * 4 * 2 * 512
+    print(f"singular (index-matched refraction) field rows skipped: {singular}")
+
+
+def test_device_bsdf_tables_f32_within_stated_bounds():
+    """The same tables from the fp32 product functions. Error of a field on a row = largest component difference /
+    max(largest component of the reference, 1e-3 x the field's median magnitude in that table), i.e. a vector error for
+    f, s_value and the unit vector s_wi; singular rows (see _singular) skipped. Stated bounds over all tables:
+      * picked lobe and delta flag: identical (the pick cdf stays double on the device);
+      * sample success flag: differs on at most 1e-3 of the queries (a sampled direction at the horizon, total internal
+        reflection decided by the last bit);
+      * ordinary rows: median <= 2e-6, 99.9th percentile <= 2e-3;
+      * hard rows -- a grazing direction (|cos| = 1e-3, where the smooth GGX lobes' alpha = 4e-6 puts D near 1e10) or
+        the index pairs (1.3614, 1.52) and (1, 1), whose refraction Jacobian cancels --: median <= 1e-5, 99th percentile <= 5e-2."""
+    errs = {f: [] for f in ("f", "pdf", "s_wi", "s_value", "s_pdf")}
+    hard = {f: [] for f in errs}
+    worst = {f: (0.0, None) for f in errs}
+    flips = total = 0
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision="f32")
+        for name, ei, fi, m, ea, eb, fr, ref, q in _bsdf_table_cases():
+            got = ctx.bsdf_table(m, q, ng=fr[0], tangent=fr[1], ns=fr[2] / np.linalg.norm(fr[2]), bitangent=fr[3], eta_a=ea, eta_b=eb)
+            assert np.array_equal(got["lobe"], ref["lobe"]) and np.array_equal(got["is_delta"], ref["is_delta"]), (name, ei, fi)
+            flips += int((got["s_ok"] != ref["s_ok"]).sum())
+            total += len(q)
+            grazing = (np.abs(q["wo"][:, 1]) < 2e-3) | (np.abs(q["wi"][:, 1]) < 2e-3)
+            both = (got["s_ok"] == 1) & (ref["s_ok"] == 1)
+            for field in errs:
+                a, b = got[field].reshape(len(q), -1), ref[field].reshape(len(q), -1)
+                rows = (both if field.startswith("s_") else np.ones(len(q), bool)) & ~_singular(b)
+                mag = np.abs(b[rows]).max(axis=1) if rows.any() else np.zeros(0)
+                floor = 1e-3 * (np.median(mag[mag > 1e-20]) if (mag > 1e-20).any() else 1.0)
+                with np.errstate(invalid="ignore"):
+                    rel = np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), floor)
+                rel = np.where(np.isfinite(rel), rel, np.inf)
+                is_hard = grazing | (ei >= 2)
+                errs[field].append(rel[rows & ~is_hard])
+                hard[field].append(rel[rows & is_hard])
+                if rows.any() and rel[rows].max() > worst[field][0]:
+                    k = int(np.flatnonzero(rows)[np.argmax(rel[rows])])
+                    worst[field] = (float(rel[k]), (name, ei, fi, k, a[k].tolist(), b[k].tolist()))
+    print(f"sample-success flips: {flips} of {total}")
+    for field in errs:
+        e, h = np.concatenate(errs[field]), np.concatenate(hard[field])
+        print(f"{field:8s} ordinary rows ({len(e)}): median {np.median(e):.2e} p99.9 {np.quantile(e, 0.999):.2e} max {e.max():.2e} | "
+              f"hard rows ({len(h)}): median {np.median(h):.2e} p99 {np.quantile(h, 0.99):.2e} max {h.max():.2e} | worst {worst[field][1]}")
+    assert flips <= 1e-3 * total
+    for field in errs:
+        e, h = np.concatenate(errs[field]), np.concatenate(hard[field])
+        assert np.median(e) <= 2e-6 and np.quantile(e, 0.999) <= 2e-3, field
+        assert np.median(h) <= 1e-5 and np.quantile(h, 0.99) <= 5e-2, field

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from common import A, R, S
+from common import A, R, S, ribbon_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -158,6 +158,16 @@ def test_error_codes():
         o = A.Options(precision=A.PRECISION_F32, sort_materials=1, epsilon=0.0, max_paths_in_flight=0, bvh_builder=A.BVH_HOST_SAH)
         setattr(o, field, value)
         assert lib.fcgpu_set_options(ctx.h, C.byref(o)) == A.E_INVALID, field
+    o = A.Options(precision=A.PRECISION_F32, sort_materials=0, epsilon=0.0, max_paths_in_flight=0, bvh_builder=A.BVH_HOST_SAH)
+    assert lib.fcgpu_set_options(ctx.h, C.byref(o)) == A.E_UNSUPPORTED  # documented as "single queue", never built: refused
+    ctx.upload_scene(sc)
+    with pytest.raises(R.FcgpuError) as e:
+        ctx.export_image("/tmp/fcgpu_nothing_rendered")  # 0 / 0 would be an image of NaNs
+    assert e.value.code == A.E_INVALID
+    for args in ((0, 0, 1), (4, 2, 2), (4, 0, 0)):
+        with pytest.raises(R.FcgpuError) as e:
+            ctx.render_bands(*args, 0, 1)
+        assert e.value.code == A.E_INVALID
     h = C.c_void_p()
     assert lib.fcgpu_create(4096, C.byref(h)) == A.E_INVALID
     ctx.close()
@@ -290,6 +300,42 @@ def test_deep_bvh_spills_the_traversal_stack_and_still_matches_the_oracle():
     assert pixel_rel_err_max(rgb, film[0]) <= 1e-9
 
 
+@pytest.mark.parametrize("n,depth", [(76, 28), (80, 29), (86, 30), (90, 31)])
+def test_bvh_whose_stack_need_is_at_the_lds_capacity(n, depth):
+    """Worst-case stack needs of 28 (the deepest the kernels without spill code take), 29 and 30 (would fit the 30 LDS
+    entries, but those kernels stop pushing at 27 occupied: they must get the SPILL instantiation) and 31: no push is
+    lost, hits equal the oracle's. Rays run along the ribbon from its big end, inside every box of the chain, which is
+    what fills the stack."""
+    from oracle import pyref
+
+    sc = ribbon_scene(n)
+    rng = np.random.default_rng(n)
+    m = 6000
+    rays = np.zeros(m, dtype=A.ray_dtype)
+    slope = rng.uniform(-0.2, 0.2, m)
+    X = 1.1 ** rng.uniform(0.7 * n, 0.98 * n, m)
+    rays["origin"] = np.stack([X, slope * X + 3.0, rng.uniform(0.1, 0.9, m)], 1)
+    d = np.stack([-np.ones(m), -slope, np.zeros(m)], 1)
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["t_max"] = np.inf
+    ref = pyref.restatement("f64").scene(sc).trace_closest(rays)
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision="f64")
+        ctx.upload_scene(sc)
+        assert ctx.counters().reserved[1] == depth
+        hits = ctx.trace_closest(rays)
+        occ = ctx.trace_any(rays)
+        ctx.render_pass(0, 2)
+        c = ctx.counters()
+    assert c.stack_overflows == 0
+    hit = ref["prim"] != 0xFFFFFFFF
+    assert hit.mean() > 0.2
+    assert np.array_equal(hits["prim"] != 0xFFFFFFFF, hit)
+    assert np.allclose(hits["t"][hit], ref["t"][hit], rtol=1e-9, atol=0)
+    assert (hits["prim"] != ref["prim"]).mean() < 0.01  # equal-t ties between neighbours of the chain only
+    assert np.array_equal(occ.astype(bool), hit)
+
+
 def pixel_rel_err_max(a, b):
     from common import pixel_rel_err
     return float(pixel_rel_err(a, b).max())
@@ -359,3 +405,68 @@ def test_texture_coordinates_outside_the_unit_square_are_clamped():
     rgb, m, c = render(sc, precision="f64", spp=4, seed=3)
     assert n == m and c.nan_samples == 0 and ref.mean() > 0
     assert (np.abs(rgb - ref).max(2) / np.maximum(np.abs(ref).max(2), 1e-3 * ref.mean())).max() <= 1e-9
+
+
+def test_stratified_renderer_runs_the_samplers_sample_count():
+    """stratified_sampler{10, seed}.get_sample_count() is floor(sqrt(10))^2 = 9 (stratified_sampler.hpp:15-16, 26-29) and
+    renderer::run_pixel renders that many samples per pixel (renderer.hpp:159): so does the drop-in renderer."""
+    sc = S.room_planes(32, 18)
+    r = R.GpuRenderer(sc, sample_count=10, sampler="stratified", seed=3)
+    r.run()
+    _, n = r.film()
+    r.close()
+    assert n == 9 * 32 * 18
+    r = R.GpuRenderer(sc, sample_count=10, sampler="random", seed=3)
+    r.run()
+    _, n = r.film()
+    r.close()
+    assert n == 10 * 32 * 18
+
+
+def test_band_sharding_is_bit_exact_and_reduces_in_the_library():
+    """fcgpu_render_bands: every rank renders its bands of rows as ONE pass; fcgpu_reduce_film sums the per-context films
+    on the device (here: four contexts on the one GPU of the box). The result equals the single-context film bit for
+    bit, for band heights that do and do not divide the frame, and more ranks than bands."""
+    sc = S.room(width=200, height=75, tess=8)
+    full, n, cf = render(sc, spp=3)
+    for band_rows, world in ((4, 4), (16, 3), (64, 4)):
+        ctxs = []
+        for rank in range(world):
+            ctx = R.GpuContext(0)
+            ctx.set_options(precision="f32")
+            ctx.upload_scene(sc)
+            ctx.set_sampler(0)
+            ctx.render_bands(band_rows, rank, world, 0, 3)
+            ctxs.append(ctx)
+        R.reduce_film(ctxs, root=1)
+        rgb, cnt = ctxs[1].read_film()
+        rays = sum(int(c.counters().closest_rays) for c in ctxs)
+        others = [c.read_film() for i, c in enumerate(ctxs) if i != 1]
+        for c in ctxs:
+            c.close()
+        assert cnt == n and np.array_equal(rgb, full), (band_rows, world)
+        assert rays == int(cf.closest_rays)
+        assert all(k == 0 and a.max() == 0 for a, k in others)  # contributors start over after a reduce
+
+
+def test_reduce_film_sums_sample_passes():
+    """Sample-pass sharding through the C-ABI reduce: two contexts render disjoint sample ranges of the full frame; the
+    reduced film equals the single-context film up to the order of the fp64 additions."""
+    sc = S.room(width=96, height=54, tess=4)
+    full, n, _ = render(sc, spp=4, precision="f64")
+    ctxs = []
+    for rank in range(2):
+        ctx = R.GpuContext(0)
+        ctx.set_options(precision="f64")
+        ctx.upload_scene(sc)
+        ctx.set_sampler(0)
+        ctx.render_pass(2 * rank, 2)
+        ctxs.append(ctx)
+    R.reduce_film(ctxs, root=0)
+    rgb, cnt = ctxs[0].read_film()
+    with pytest.raises(R.FcgpuError) as e:
+        R.reduce_film([ctxs[0], ctxs[0]], root=0)
+    assert e.value.code == A.E_INVALID
+    for c in ctxs:
+        c.close()
+    assert cnt == n and np.allclose(rgb, full, rtol=1e-13, atol=0)

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from common import A, R, S
+from common import A, R, S, ribbon_scene
 from oracle import pyref
 
 
@@ -118,3 +118,11 @@ def test_every_scene_builder_flattens_on_the_host():
         sc = S.random_scene(1, 32, 24) if name == "random_scene" else build(width=32, height=24)
         st = R.check_scene(sc)
         assert st.primitives == sc.primitive_total(), name
+
+
+def test_ribbon_scenes_straddle_the_lds_stack_capacity():
+    """The GPU test of the 28 / 29 / 30 / 31-entry window (test_bvh_whose_stack_need_is_at_the_lds_capacity) relies on
+    these depths; fcgpu_check_scene builds the same hierarchy on the host."""
+    for n, depth in ((76, 28), (80, 29), (86, 30), (90, 31)):
+        assert R.check_scene(ribbon_scene(n)).max_stack == depth
+
