@@ -111,6 +111,20 @@ def main():
         print("film", name, {k: float(v.mean()) for k, v in out.items() if k.endswith("rgb_sum")})
         rs.close()
 
+    # the headline configuration itself (BASELINE.json configs[1]: room, Forward MIS, 1920x1080, the bench's tess 64): the centre
+    # 240 x 135 pixels of the full frame at 16 spp, seed 0 = the sample streams bench.py renders. Only the crop is stored.
+    if wanted("crop_headline"):
+        kw = dict(width=1920, height=1080, tess=64)
+        tile = ((1920 - 240) // 2, (1080 - 135) // 2, 240, 135)
+        rs = ref.scene(S.room(**kw))
+        rgb, n, st = rs.render(16, integrator=A.INTEGRATOR_MIS, max_path_length=10, threads=8, seed=0, tile=tile)
+        x0, y0, w, h = tile
+        np.savez_compressed(os.path.join(OUT, "crop_headline.npz"), builder="room", kwargs=repr(kw), spp=16, max_path_length=10, seed=0,
+                            tile=np.array(tile), mis_rgb_sum=rgb[y0:y0 + h, x0:x0 + w], mis_count=np.uint64(n),
+                            mis_rays=np.array([st.closest_rays, st.any_rays, st.any_occluded, st.nan_samples], np.uint64), **meta)
+        print("crop headline", float(rgb.mean()), n)
+        rs.close()
+
     # ray / hit sets: the rays the reference itself casts (natural distribution) + uniform random rays
     for name, builder, kw, lo, hi in (("room_t6", "room", dict(width=32, height=18, tess=6), [-11.5, 0.2, -9.5], [11.5, 7.8, 19.5]),
                                       ("zoo", "primitives_zoo", dict(width=24, height=24), [-6, 0.1, -5], [6, 6, 8])):
