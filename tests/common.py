@@ -54,3 +54,38 @@ def ribbon_scene(n, g=1.1):
     sc.set_camera((20.0, 6.0, 6.0), (np.radians(40.0), np.radians(180.0), 0.0), np.radians(60.0), 48, 32)
     return sc
 
+
+def cards_scene(n, g=1.2):
+    """n right triangles ("cards") in the planes z = g^k, corner at (-g^k, -g^k), legs 1.5 g^k: every card's box
+    contains the z axis, its triangle only covers x + y <= -g^k / 2. The SAH tree is a chain (the biggest card is
+    peeled off at every level), and a ray up the z axis from the small end pierces every box and misses the triangles:
+    at each wide node the near child is the interior remainder and the (far) leaf children pile up, so the traversal
+    stack really reaches the hierarchy's worst case (fcgpu_scene_stats.max_stack ~ n / 2.5). A quad behind the last card
+    catches those rays. tests/test_host_logic.py pins the depths the GPU tests rely on."""
+    s = g ** np.arange(n, dtype=np.float64)
+    pos = np.zeros((3 * n + 4, 3), np.float32)
+    pos[0:3 * n:3] = np.stack([-s, -s, s], 1)
+    pos[1:3 * n:3] = np.stack([0.5 * s, -s, s], 1)
+    pos[2:3 * n:3] = np.stack([-s, 0.5 * s, s], 1)
+    S_, Z = 2.0 * s[-1], 2.0 * s[-1]
+    pos[3 * n:] = [[-S_, -S_, Z], [S_, -S_, Z], [S_, S_, Z], [-S_, S_, Z]]
+    idx = np.concatenate([np.arange(3 * n, dtype=np.uint32), np.array([3 * n, 3 * n + 1, 3 * n + 2, 3 * n, 3 * n + 2, 3 * n + 3], np.uint32)])
+    sc = S.Scene()
+    sc.entity(sc.mesh(pos, idx), sc.diffuse((0.7, 0.7, 0.7)))
+    sc.set_env((1.0, 0.9, 0.8))
+    sc.set_camera((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), np.radians(60.0), 32, 32)
+    return sc
+
+
+def cards_rays(n_rays, seed):
+    """Rays up the z axis (tilted by up to 1e-3 towards +x, +y: exactly axis-parallel rays meet fp32's clamp of 1 / d at
+    coordinates of 1e9) from just below the smallest card, at random (x, y) in [-0.9, 0.9]^2: those with x + y below
+    -0.5 hit the first cards, the others miss every card and end on the backstop after filling the stack."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n_rays, dtype=A.ray_dtype)
+    xy = rng.uniform(-0.9, 0.9, (n_rays, 2))
+    rays["origin"] = np.stack([xy[:, 0], xy[:, 1], np.full(n_rays, 0.5)], 1)
+    d = np.concatenate([1e-3 * rng.uniform(0, 1, (n_rays, 2)), np.ones((n_rays, 1))], 1)
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["t_max"] = np.inf
+    return rays

@@ -37,7 +37,9 @@ def test_headline_crop_f64_matches_reference():
     rgb, n, c = _render("f64", z)
     assert n == int(z["mis_count"]) and c.stack_overflows == 0
     assert pixel_rel_err(rgb, z["mis_rgb_sum"]).max() <= 1e-9
-    assert c.closest_rays == int(z["mis_rays"][0]) and abs(int(c.shadow_rays) - int(z["mis_rays"][1])) <= 8
+    # visibility rays are cast where bsdf->evaluate() is non-zero, a test rounding decides at grazing light directions (device
+    # libm against glibc): 160 of 4.4 M rays differ here, all of them occluded or carrying zero radiance (the film is equal)
+    assert c.closest_rays == int(z["mis_rays"][0]) and abs(int(c.shadow_rays) - int(z["mis_rays"][1])) <= 1e-4 * int(z["mis_rays"][1])
     assert c.nan_samples == int(z["mis_rays"][3])
 
 

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from common import A, R, S, ribbon_scene
+from common import A, R, S, cards_rays, cards_scene, ribbon_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -300,40 +300,33 @@ def test_deep_bvh_spills_the_traversal_stack_and_still_matches_the_oracle():
     assert pixel_rel_err_max(rgb, film[0]) <= 1e-9
 
 
-@pytest.mark.parametrize("n,depth", [(76, 28), (80, 29), (86, 30), (90, 31)])
+@pytest.mark.parametrize("n,depth", [(58, 28), (60, 29), (66, 30), (67, 31), (72, 32)])
 def test_bvh_whose_stack_need_is_at_the_lds_capacity(n, depth):
     """Worst-case stack needs of 28 (the deepest the kernels without spill code take), 29 and 30 (would fit the 30 LDS
-    entries, but those kernels stop pushing at 27 occupied: they must get the SPILL instantiation) and 31: no push is
-    lost, hits equal the oracle's. Rays run along the ribbon from its big end, inside every box of the chain, which is
-    what fills the stack."""
+    entries, but those kernels stop pushing once 27 are occupied: such scenes must get the SPILL instantiation), 31
+    and 32 -- on a scene whose rays really fill the stack to that worst case (common.cards_scene): no push is lost,
+    hits equal the oracle's in fp64 and, up to edge ties, in fp32."""
     from oracle import pyref
 
-    sc = ribbon_scene(n)
-    rng = np.random.default_rng(n)
-    m = 6000
-    rays = np.zeros(m, dtype=A.ray_dtype)
-    slope = rng.uniform(-0.2, 0.2, m)
-    X = 1.1 ** rng.uniform(0.7 * n, 0.98 * n, m)
-    rays["origin"] = np.stack([X, slope * X + 3.0, rng.uniform(0.1, 0.9, m)], 1)
-    d = np.stack([-np.ones(m), -slope, np.zeros(m)], 1)
-    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
-    rays["t_max"] = np.inf
+    sc = cards_scene(n)
+    rays = cards_rays(6000, n)
     ref = pyref.restatement("f64").scene(sc).trace_closest(rays)
-    with R.GpuContext(0) as ctx:
-        ctx.set_options(precision="f64")
-        ctx.upload_scene(sc)
-        assert ctx.counters().reserved[1] == depth
-        hits = ctx.trace_closest(rays)
-        occ = ctx.trace_any(rays)
-        ctx.render_pass(0, 2)
-        c = ctx.counters()
-    assert c.stack_overflows == 0
-    hit = ref["prim"] != 0xFFFFFFFF
-    assert hit.mean() > 0.2
-    assert np.array_equal(hits["prim"] != 0xFFFFFFFF, hit)
-    assert np.allclose(hits["t"][hit], ref["t"][hit], rtol=1e-9, atol=0)
-    assert (hits["prim"] != ref["prim"]).mean() < 0.01  # equal-t ties between neighbours of the chain only
-    assert np.array_equal(occ.astype(bool), hit)
+    assert (ref["prim"] >= n).mean() > 0.5 and (ref["prim"] < n).mean() > 0.1  # backstop after a full stack / card hits
+    for precision in ("f64", "f32"):
+        with R.GpuContext(0) as ctx:
+            ctx.set_options(precision=precision)
+            ctx.upload_scene(sc)
+            assert ctx.counters().reserved[1] == depth
+            hits = ctx.trace_closest(rays)
+            occ = ctx.trace_any(rays)
+            ctx.render_pass(0, 2)
+            c = ctx.counters()
+        assert c.stack_overflows == 0
+        assert (int(c.reserved[5]) > 0) == (depth > 30)  # pushes beyond the LDS entries happen exactly when the tree needs them
+        mismatch = hits["prim"] != ref["prim"]
+        assert mismatch.sum() == 0 if precision == "f64" else mismatch.mean() < 0.01
+        assert np.allclose(hits["t"][~mismatch], ref["t"][~mismatch], rtol=1e-9 if precision == "f64" else 1e-5, atol=0)
+        assert occ.all()
 
 
 def pixel_rel_err_max(a, b):

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from common import A, R, S, ribbon_scene
+from common import A, R, S, cards_scene, ribbon_scene
 from oracle import pyref
 
 
@@ -120,9 +120,9 @@ def test_every_scene_builder_flattens_on_the_host():
         assert st.primitives == sc.primitive_total(), name
 
 
-def test_ribbon_scenes_straddle_the_lds_stack_capacity():
-    """The GPU test of the 28 / 29 / 30 / 31-entry window (test_bvh_whose_stack_need_is_at_the_lds_capacity) relies on
-    these depths; fcgpu_check_scene builds the same hierarchy on the host."""
-    for n, depth in ((76, 28), (80, 29), (86, 30), (90, 31)):
-        assert R.check_scene(ribbon_scene(n)).max_stack == depth
-
+def test_card_scenes_straddle_the_lds_stack_capacity():
+    """The GPU tests of the 28 .. 32-entry window (test_bvh_whose_stack_need_is_at_the_lds_capacity) and of the
+    no-allocation entry point (47 of its 62 entries) rely on these depths; fcgpu_check_scene builds the same hierarchy."""
+    for n, depth in ((58, 28), (60, 29), (66, 30), (67, 31), (72, 32), (120, 47)):
+        assert R.check_scene(cards_scene(n)).max_stack == depth
+    assert R.check_scene(ribbon_scene(420)).max_stack > 62
