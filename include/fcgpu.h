@@ -376,6 +376,20 @@ int fcgpu_bsdf_table(fcgpu_ctx* ctx, const fcgpu_material* material, const doubl
                      const double* ns, const double* bitangent, double eta_a, double eta_b, uint64_t n,
                      const fcgpu_bsdf_query* queries, fcgpu_bsdf_result* results);
 
+/* The no-allocation variant of fcgpu_trace_closest_device. It has NO counterpart in the reference; it exists for callers
+ * that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation. Same
+ * kernel, same results (bit for bit); the kernel's scratch -- its statistics words and, for hierarchies deeper than the
+ * LDS stack, the per-lane spill columns -- lives in a static device array of 8 MiB + 256 B per GPU that the library holds
+ * until the process ends, and the launch uses a fixed grid of 256 blocks. Calls no hipMalloc, hipFree or other
+ * allocating routine; asynchronous on the context's stream like the _device entry point.
+ * Limits (FCGPU_E_LIMIT beyond them): n <= FCGPU_NOALLOC_MAX_RAYS; the scene's worst-case traversal stack
+ * (fcgpu_counters.reserved[1]) <= FCGPU_NOALLOC_MAX_STACK.
+ * Every context on one GPU shares that GPU's array: calls that overlap on one GPU (two contexts, two threads) race on
+ * it. Run them one after the other (stream order on one context is enough). */
+#define FCGPU_NOALLOC_MAX_RAYS (1ull << 30)
+#define FCGPU_NOALLOC_MAX_STACK 62
+int fcgpu_trace_closest_noalloc(fcgpu_ctx* ctx, uint64_t n, const fcgpu_ray* rays_dev, fcgpu_hit* hits_dev);
+
 /* Film. Replaces render_target (render_target.hpp:15-23, 30-38) and the sum/count that
  * renderer::export_image divides (renderer.hpp:118-135): rgb_sum[(y*W + x)*3 + c] / sample_count
  * is the pixel value the reference writes. Synchronous.                                      */

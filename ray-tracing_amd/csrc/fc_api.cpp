@@ -68,6 +68,7 @@ struct fcgpu_ctx
     uint64_t film_elems{};
     QueueCounters* counters{};
     unsigned long long* stats{};
+    unsigned char* noalloc_scratch{};  // this device's copy of the static scratch array (fc_kernels.hip), set at create
     uint64_t samples{};
     uint64_t launches{};
     int grid{};
@@ -681,6 +682,7 @@ extern "C"
         if((e = hipMalloc(reinterpret_cast<void**>(&c->stats), sizeof(unsigned long long) * ST_COUNT)) != hipSuccess) return bail(e, "hipMalloc");
         if((e = hipMemset(c->counters, 0, sizeof(QueueCounters))) != hipSuccess) return bail(e, "hipMemset");
         if((e = hipMemset(c->stats, 0, sizeof(unsigned long long) * ST_COUNT)) != hipSuccess) return bail(e, "hipMemset");
+        if((e = noalloc_scratch_for_device(device, &c->noalloc_scratch)) != hipSuccess) return bail(e, "hipGetSymbolAddress(scratch)");
         hipDeviceProp_t prop{};
         if((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
         c->grid = std::max(1, prop.multiProcessorCount) * 8;
@@ -902,6 +904,41 @@ extern "C"
     {
         if(c && !occluded_dev && n) return fail(c, FCGPU_E_INVALID, "null output");
         return trace_device(c, n, rays_dev, nullptr, occluded_dev);
+    }
+
+    // The no-allocation variant of fcgpu_trace_closest_device (include/fcgpu.h): same kernel, its scratch in the static
+    // device array whose per-device address fcgpu_create looked up. No hipMalloc / hipFree on any path.
+    int fcgpu_trace_closest_noalloc(fcgpu_ctx* c, uint64_t n, const fcgpu_ray* rays_dev, fcgpu_hit* hits_dev)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+        if(n == 0) return FCGPU_OK;
+        if(!rays_dev || !hits_dev) return fail(c, FCGPU_E_INVALID, "null buffer");
+        if(n > FCGPU_NOALLOC_MAX_RAYS) return fail(c, FCGPU_E_LIMIT, "fcgpu_trace_closest_noalloc: more than FCGPU_NOALLOC_MAX_RAYS (2^30) rays in one call");
+        const bool deep = c->stack_spill != nullptr;  // the scene runs the SPILL instantiations (set at upload)
+        if(c->flat.max_stack > static_cast<uint32_t>(STACK_CAP) + NOALLOC_SPILL_ENTRIES)
+            return fail(c, FCGPU_E_LIMIT, "fcgpu_trace_closest_noalloc: the hierarchy needs more than FCGPU_NOALLOC_MAX_STACK (62) traversal-stack entries; use fcgpu_trace_closest_device");
+        if(!c->noalloc_scratch) return fail(c, FCGPU_E_HIP, "no scratch address for this device");
+        HIP_TRY(c, hipSetDevice(c->device));
+        unsigned long long* stats = reinterpret_cast<unsigned long long*>(c->noalloc_scratch);
+        // the array keeps the last call's contents: the counters must start at zero (the spill columns need not)
+        HIP_TRY(c, hipMemsetAsync(stats, 0, NOALLOC_STATS_BYTES, c->stream));
+        const LaunchCfg L{c->stream, static_cast<int>(NOALLOC_LANES / 256u)};
+        auto run = [&](auto S) {
+            S.epsilon = static_cast<decltype(S.epsilon)>(effective_epsilon(c));
+            S.stack_spill = deep ? reinterpret_cast<uint32_t*>(c->noalloc_scratch + NOALLOC_STATS_BYTES) : nullptr;
+            S.stack_spill_stride = NOALLOC_LANES;
+            launch_trace(L, S, n, rays_dev, hits_dev, static_cast<uint8_t*>(nullptr), stats);
+        };
+        if(c->opt.precision == FCGPU_PRECISION_F64)
+            run(c->s64);
+        else
+            run(c->s32);
+        launch_fold_stats(L, c->stats, stats);
+        c->launches += 2;
+        const hipError_t e = hipGetLastError();
+        if(e != hipSuccess) return hip_fail(c, e, "trace launch");
+        return FCGPU_OK;
     }
 
     // ------------------------------------------------------------------ multi-GPU film reduce (renderer.hpp:125-135)

@@ -58,6 +58,20 @@ namespace fcg
     void launch_bsdf_table(const LaunchCfg& L, const LobeRec<R>* lobes, int lobe_count, const double* frame, double eta_a, double eta_b, uint64_t n,
                            const fcgpu_bsdf_query* queries, fcgpu_bsdf_result* results);
 
+    // ---- fcgpu_trace_closest_noalloc: the variant of fcgpu_trace_closest_device for callers that cannot allocate.
+    // Its scratch (the traversal kernel's statistics words and, for deep hierarchies, the spill columns of the traversal
+    // stack) is a file-scope __device__ array in fc_kernels.hip instead of hipMalloc'ed memory: 256 bytes of counters +
+    // NOALLOC_SPILL_ENTRIES x NOALLOC_LANES words = 8 MiB + 256 B per GPU, held until the process ends.
+    constexpr uint32_t NOALLOC_LANES = 256u * 256u;       // the variant's grid: 256 blocks of 256 lanes
+    constexpr uint32_t NOALLOC_SPILL_ENTRIES = 32u;       // stack entries beyond STACK_CAP per lane
+    constexpr size_t NOALLOC_STATS_BYTES = 256;
+    constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_STATS_BYTES + sizeof(uint32_t) * NOALLOC_SPILL_ENTRIES * NOALLOC_LANES;
+    // device address of this device's copy of the scratch array (hipGetSymbolAddress, once per device; the device must
+    // be current). Returns hipSuccess or the HIP error.
+    hipError_t noalloc_scratch_for_device(int device, unsigned char** out);
+    // adds the statistics words a no-alloc launch left in the scratch to the context's counters
+    void launch_fold_stats(const LaunchCfg& L, unsigned long long* dst, const unsigned long long* src);
+
     template<typename R> void launch_trace(const LaunchCfg& L, const SceneDev<R>& S, uint64_t n, const fcgpu_ray* rays,
                                            fcgpu_hit* hits, uint8_t* occluded, unsigned long long* stats);
 }

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/fcgpu_sampler.h"
@@ -1148,6 +1149,41 @@ namespace fcg
         wave_stat_add(stats, ST_STACK_OVERFLOW, n_overflow.lost);
         wave_stat_add(stats, ST_STACK_SPILL, n_overflow.spilled);
     }
+
+    // ------------------------------------------------------------------ scratch of fcgpu_trace_closest_noalloc
+#ifndef FCG_ONLY_F64
+    // One copy per GPU the library runs on, at that GPU's own address. In host code the NAME is only a stand-in for the
+    // symbol: the address kernels may use comes from hipGetSymbolAddress, below, and nothing else is ever passed on.
+    static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+    hipError_t noalloc_scratch_for_device(int device, unsigned char** out)
+    {
+        constexpr int MAX_DEVICES = 64;
+        static std::mutex lock;
+        static unsigned char* address[MAX_DEVICES] = {};
+        *out = nullptr;
+        if(device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> guard(lock);
+        if(!address[device])
+        {
+            void* p = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // of the CURRENT device: the caller made `device` current
+            if(e != hipSuccess) return e;
+            address[device] = static_cast<unsigned char*>(p);
+        }
+        *out = address[device];
+        return hipSuccess;
+    }
+
+    __global__ void k_fold_stats(unsigned long long* dst, const unsigned long long* src)
+    {
+        if(threadIdx.x < ST_COUNT && src[threadIdx.x]) atomicAdd(&dst[threadIdx.x], src[threadIdx.x]);
+    }
+    void launch_fold_stats(const LaunchCfg& L, unsigned long long* dst, const unsigned long long* src)
+    {
+        hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, L.stream, dst, src);
+    }
+#endif
 
     // ------------------------------------------------------------------ multi-GPU film sum (fcgpu_reduce_film)
 #ifndef FCG_ONLY_F64

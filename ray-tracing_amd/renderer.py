@@ -49,6 +49,7 @@ def load_library():
         "fcgpu_trace_any": (i32, [vp, u64, vp, vp]),
         "fcgpu_trace_closest_device": (i32, [vp, u64, vp, vp]),
         "fcgpu_trace_any_device": (i32, [vp, u64, vp, vp]),
+        "fcgpu_trace_closest_noalloc": (i32, [vp, u64, vp, vp]),
         "fcgpu_clear_film": (i32, [vp]),
         "fcgpu_read_film": (i32, [vp, vp, P(u64)]),
         "fcgpu_film_device_ptr": (i32, [vp, P(vp), P(u64)]),
@@ -187,6 +188,10 @@ class GpuContext:
 
     def trace_closest_device(self, n, rays_ptr, hits_ptr):
         self._check(self.lib.fcgpu_trace_closest_device(self.h, n, rays_ptr, hits_ptr))
+
+    def trace_closest_noalloc(self, n, rays_ptr, hits_ptr):
+        """fcgpu_trace_closest_noalloc: like trace_closest_device, scratch in the library's static device array."""
+        self._check(self.lib.fcgpu_trace_closest_noalloc(self.h, n, rays_ptr, hits_ptr))
 
     def trace_any_device(self, n, rays_ptr, out_ptr):
         self._check(self.lib.fcgpu_trace_any_device(self.h, n, rays_ptr, out_ptr))
