@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: room scene, Forward MIS, 1920x1080 (BASELINE.json configs[1]).
 
-A "step" renders `--spp-per-step` samples per pixel of the full frame through the HIP wavefront
-path (generate -> {extend, sort, shade<lobe>, shadow} x 10 -> accumulate), in batches of up to 2^27 paths
-(16 spp); the default 16 steps x 64 spp are the whole 1024-spp job. All inputs (scene, BVH, queues) are resident in HBM before the
-timed region starts; the film stays on the device (read-back is outside the timed region for
-N = 1, the RCCL film reduce is inside it for N > 1).
+A "step" renders `--spp-per-step` samples per pixel of the full frame through the HIP wavefront path
+(generate -> {extend, sort, shade<lobe>, shadow} x 10 -> accumulate) in batches of up to 2^27 paths (64 spp of a
+1080p frame); the default 16 steps x 64 spp are the whole 1024-spp job. All inputs (scene, BVH, queues) are resident
+in HBM before the timed region starts; the film stays on the device (read-back is outside the timed region for N = 1,
+the RCCL film reduce is inside it for N > 1).
 
-N > 1 (launched by torch.distributed.run, one process per GPU): sample-pass sharding -- every rank
-renders the full frame for its own sample indices (weak scaling: per-GPU work is fixed), then the
-per-rank films are summed with one RCCL reduce over xGMI, the analogue of the per-worker film
-sum of renderer::export_image (renderer.hpp:129-133).
+`--gpus N` with N > 1 starts N ranks itself (python -m torch.distributed.run, one process per GPU, started BEFORE
+anything in this process touches a GPU) and relays rank 0's JSON line; under an external torch.distributed.run
+(WORLD_SIZE set) it is a rank. Two partitionings of the job, the multi-GPU analogue of the reference's N worker
+threads whose films are summed at export (renderer.hpp:65-81, 125-135):
+  --shard samples (default; weak scaling)  every rank renders the full frame for its own sample indices, the films
+                                           are summed with one RCCL reduce over xGMI;
+  --shard tiles   (strong scaling)         ONE job of steps x spp samples per pixel; rank r renders the bands of
+                                           --band-rows rows with band % N == r (fcgpu_render_bands: full-width tiles
+                                           dealt round-robin, one pass per step), the same reduce gathers the disjoint
+                                           films, and rank 0 re-renders a few bands it does not own and checks them
+                                           against the gathered film bit for bit.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0 and exits non-zero when the fp32 parity gate beside the speed fails.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,16 +37,66 @@ PIPELINE_BYTES_PER_RAY = 112.0  # 32 ray in + 16 hit out + 64 pa
 EXTEND_BYTES_PER_RAY = 48.0     # the extend kernel's own share of it (ray record in, hit record out)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 (vector)
-# Fabric traffic of k_extend per ray, from the rocprofv3 PMC passes kept under profiles/
-# (r01_pmc_v14_tcc_*.txt: TCC_EA0_RDREQ all 128-byte requests, TCC_EA0_WRREQ split 64/32 bytes; this is
-# what FETCH_SIZE doubled + WRITE_SIZE give on gfx950): (1.12e8*128 + 2.07e8*64 + 1.60e8*32) B over
-# 3.52e8 rays (123 B/ray before the queue columns went to streaming accesses). Counted at the L2's memory side, i.e. Infinity-Cache hits included.
-EXTEND_TRAFFIC_BYTES_PER_RAY = 87.0
+# rocprofv3 PMC passes of THIS build at the bench's own batch size, reduced to per-kernel numbers by
+# tools/pmc_summary.py; the passes themselves are kept under profiles/ (named in the file's "source")
+PMC_SUMMARY = os.path.join(ROOT, "ray-tracing_amd", "pmc_summary.json")
+
+# fp32 parity gate (same sample streams, against the CPU baseline's film): thresholds as a function of the samples per
+# pixel, because a pixel is the sum of its paths and ONE path whose discrete decision flips on a rounding (a hit at a
+# triangle edge, a Fresnel pick) moves it: measured 1.14 % of the pixels beyond 1e-2 at 16 spp (7e-4 per path).
+PARITY_MEDIAN_REL_ERR = 5e-6
+PARITY_BEYOND_1E2_PER_SPP = 1.1e-3   # fraction within 1e-2 >= 1 - 1.1e-3 * spp
+PARITY_MEAN_RATIO = 1e-3
+PARITY_REL_MSE = 1e-3
+
+
+def launch_ranks(args):
+    """--gpus N without an external launcher: N fresh ranks via torch.distributed.run. Nothing here touches a GPU
+    (counting devices does not initialise HIP), so no process that holds a GPU context is ever replaced."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible: refusing to run fewer ranks than asked", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode == 0 and line is None:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(S, A, args):
-    """The reference (oracle/_ref, kind "reference") or the CPU restatement (kind "port") timed on
-    the host cores on a bounded sample of the same workload: a centred crop of the same frame."""
+    """The reference (oracle/_ref, kind "reference") or the CPU restatement (kind "port") timed on the host cores on a
+    bounded sample of the same workload: a centred crop of the same frame, same scene and sample streams. Two legs
+    on all cores (the first one's film is what the parity gate compares) sized for >= 30 s together, and one leg on a
+    single thread."""
     from oracle import pyref
 
     scene = S.room(args.width, args.height, tess=args.tess)
@@ -47,25 +106,39 @@ def cpu_baseline(S, A, args):
     sc = backend.scene(scene)
     tw, th = args.width // 4, args.height // 4
     tile = ((args.width - tw) // 2, (args.height - th) // 2, tw, th)
-    spp = args.cpu_spp
-    rgb, n, st = sc.render(spp, integrator=A.INTEGRATOR_MIS, max_path_length=10, seed=0, tile=tile, threads=cores)
-    rays = st.closest_rays + st.any_rays
+    legs = []
+    rgb, n, st = sc.render(args.parity_spp, integrator=A.INTEGRATOR_MIS, max_path_length=10, seed=0, tile=tile, threads=cores)
+    legs.append((n, st))
+    if args.cpu_spp > args.parity_spp:
+        _, n2, st2 = sc.render(args.cpu_spp - args.parity_spp, integrator=A.INTEGRATOR_MIS, max_path_length=10, seed=0, tile=tile,
+                               threads=cores, sample_begin=args.parity_spp)
+        legs.append((n2, st2))
+    seconds = sum(s.seconds for _, s in legs)
+    samples = sum(k for k, _ in legs)
+    rays = sum(s.closest_rays + s.any_rays for _, s in legs)
     out = {
-        "value": rays / st.seconds / 1e6, "unit": "Mrays/s", "samples_per_s": n / st.seconds, "cores": cores, "kind": kind,
-        "seconds": st.seconds, "rays_per_sample": rays / n,
-        "sample": f"centre crop {tw}x{th} of the {args.width}x{args.height} frame, {spp} spp, Forward MIS, max_path_length 10, same scene and sample streams",
+        "value": rays / seconds / 1e6, "unit": "Mrays/s", "samples_per_s": samples / seconds, "cores": cores, "kind": kind,
+        "seconds": seconds, "rays_per_sample": rays / samples, "cpu_model": cpu_model(),
+        "sample": f"centre crop {tw}x{th} of the {args.width}x{args.height} frame, {args.cpu_spp} spp, Forward MIS, max_path_length 10, "
+                  "same scene and sample streams",
     }
-    return out, rgb, tile, int(st.nan_samples)
+    if args.cpu_1t_spp > 0:
+        _, n1, st1 = sc.render(args.cpu_1t_spp, integrator=A.INTEGRATOR_MIS, max_path_length=10, seed=0, tile=tile, threads=1)
+        r1 = st1.closest_rays + st1.any_rays
+        out["one_thread"] = {"value": r1 / st1.seconds / 1e6, "unit": "Mrays/s", "samples_per_s": n1 / st1.seconds, "seconds": st1.seconds,
+                             "sample": f"the same crop, {args.cpu_1t_spp} spp"}
+    return out, rgb, tile, int(legs[0][1].nan_samples)
 
 
 def parity_gate(ctx, A, args, ref_rgb, tile, ref_nan, kind):
     """The correctness gate beside the speed: the GPU renders the CPU baseline's crop with the same
-    sample indices and streams (untimed); per-pixel radiance is compared with the CPU result."""
+    sample indices and streams (untimed); per-pixel radiance is compared with the CPU result against the thresholds
+    stated at the top of this file."""
     import numpy as np
 
     ctx.clear_film()
     ctx.reset_counters()
-    ctx.render_pass(0, args.cpu_spp, A.INTEGRATOR_MIS, 10, True, tile)
+    ctx.render_pass(0, args.parity_spp, A.INTEGRATOR_MIS, 10, True, tile)
     rgb, _ = ctx.read_film()
     c = ctx.counters()
     x0, y0, w, h = tile
@@ -73,12 +146,48 @@ def parity_gate(ctx, A, args, ref_rgb, tile, ref_nan, kind):
     floor = 1e-3 * max(float(np.abs(b).mean()), 1e-30)
     rel = np.abs(a - b).max(axis=2) / np.maximum(np.abs(b).max(axis=2), floor)
     mse = float(np.mean((a - b) ** 2) / max(float(np.mean(b)) ** 2, 1e-30))
-    return {
-        "against": kind, "pixels": int(w * h), "spp": args.cpu_spp, "dtype": args.precision,
+    out = {
+        "against": kind, "pixels": int(w * h), "spp": args.parity_spp, "dtype": args.precision,
         "median_rel_err": float(np.median(rel)), "fraction_within_1e-2": float((rel <= 1e-2).mean()),
+        "fraction_within_1e-3": float((rel <= 1e-3).mean()),
         "mean_ratio": float(a.mean() / b.mean()), "rel_mse": mse,
         "nan_samples": [int(c.nan_samples), ref_nan], "stack_overflows": int(c.stack_overflows),
     }
+    f64 = args.precision == "f64"
+    th = {
+        "median_rel_err_max": 1e-12 if f64 else PARITY_MEDIAN_REL_ERR,
+        "fraction_within_1e-2_min": 1.0 if f64 else 1.0 - PARITY_BEYOND_1E2_PER_SPP * args.parity_spp,
+        "mean_ratio_tol": 1e-9 if f64 else PARITY_MEAN_RATIO, "rel_mse_max": 1e-18 if f64 else PARITY_REL_MSE,
+    }
+    out["thresholds"] = th
+    out["pass"] = bool(out["median_rel_err"] <= th["median_rel_err_max"] and out["fraction_within_1e-2"] >= th["fraction_within_1e-2_min"]
+                       and abs(out["mean_ratio"] - 1.0) <= th["mean_ratio_tol"] and mse <= th["rel_mse_max"]
+                       and out["nan_samples"][0] == out["nan_samples"][1] and out["stack_overflows"] == 0)
+    return out
+
+
+def f64_leg(R, S, A, args, device):
+    """The reference-precision rate on the same workload (a short extra leg after the timed region): fp64 kernels,
+    the reference's own arithmetic (matches it per pixel to 1e-9, tests/test_gpu_headline.py)."""
+    spp = 32  # 2^26 paths: the fp64 queues of one 64-spp batch would be 57 GB
+    ctx = R.GpuContext(device)
+    ctx.set_options(precision="f64")
+    ctx.upload_scene(S.room(args.width, args.height, tess=args.tess))
+    ctx.set_sampler(0)
+    ctx.render_pass(0, 4)
+    ctx.sync()
+    ctx.clear_film()
+    ctx.reset_counters()
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.render_pass(4, spp)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    c = ctx.counters()
+    ctx.close()
+    n = args.width * args.height * spp
+    return {"dtype": "f64", "spp": spp, "samples_per_s": n / dt, "value": (c.closest_rays + c.shadow_rays) / dt / 1e6, "unit": "Mrays/s",
+            "nan_samples": int(c.nan_samples)}
 
 
 def main():
@@ -91,20 +200,37 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tess", type=int, default=64)
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--cpu-spp", type=int, default=48)
+    ap.add_argument("--shard", default="samples", choices=["samples", "tiles"])
+    ap.add_argument("--band-rows", type=int, default=4, help="tile sharding: rows per band (full-width tiles dealt round-robin)")
+    ap.add_argument("--cpu-spp", type=int, default=176, help="CPU baseline: samples per pixel of the crop on all cores (>= 30 s of work)")
+    ap.add_argument("--cpu-1t-spp", type=int, default=4, help="CPU baseline: samples per pixel of the crop on one thread (0 = skip)")
+    ap.add_argument("--parity-spp", type=int, default=16, help="samples per pixel the parity gate compares (first leg of the CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64-leg", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stage timing (roofline leg)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): the two must agree", file=sys.stderr)
+        sys.exit(2)
     dist = None
     torch = None
     if "WORLD_SIZE" in os.environ:  # launched by torch.distributed.run (also exercised with one rank)
         import torch
         import torch.distributed as dist
 
+        if torch.cuda.device_count() <= local:
+            print(f"bench.py: rank {rank} has no GPU {local} ({torch.cuda.device_count()} visible)", file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -123,9 +249,17 @@ def main():
         film = torch.as_tensor(ctx.film_device_view(), device=torch.device("cuda", local))
 
     spp = args.spp_per_step
-    # sample indices: rank r owns [r * total, (r + 1) * total)
     total_steps = args.warmup + args.steps
-    base = rank * total_steps * spp
+    tiles = args.shard == "tiles"
+    # samples: rank r owns the sample indices [r * total, (r + 1) * total) of every pixel;
+    # tiles:   every rank renders the same sample indices [0, total) of the pixels it owns
+    base = 0 if tiles else rank * total_steps * spp
+
+    def render_step(k):
+        if tiles:
+            ctx.render_bands(args.band_rows, rank, world, base + k * spp, spp)
+        else:
+            ctx.render_pass(base + k * spp, spp)
 
     def barrier():
         ctx.sync()
@@ -135,11 +269,11 @@ def main():
             torch.cuda.synchronize()
 
     for w in range(args.warmup):
-        ctx.render_pass(base + w * spp, spp)
+        render_step(w)
     ctx.sync()
     if dist is not None and args.warmup > 0:
         # warm the collective too: RCCL sets its reduce channels up on first use, which belongs to warm-up
-        D.reduce_film(film, args.width * args.height * spp * args.warmup, dst=0)
+        D.reduce_film(film, 0, dst=0)
         torch.cuda.synchronize()
     ctx.clear_film()
     ctx.reset_counters()
@@ -150,18 +284,19 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ctx.render_pass(base + (args.warmup + k) * spp, spp)
+        render_step(args.warmup + k)
     if dist is not None:
         ctx.sync()
-        D.reduce_film(film, args.width * args.height * spp * args.steps, dst=0)
+        D.reduce_film(film, 0, dst=0)
     barrier()
     elapsed = time.perf_counter() - t0
 
     c = ctx.counters()
     stages = ctx.stage_times() if not args.no_profile else {}
     ctx.set_profiling(False)
-    samples = args.width * args.height * spp * args.steps
+    local_samples = int(c.samples)
     rays = c.closest_rays + c.shadow_rays
+    samples = local_samples
     if dist is not None:
         t = torch.tensor([elapsed, float(samples), float(rays)], dtype=torch.float64, device=torch.device("cuda", local))
         tmax = t.clone()
@@ -169,35 +304,79 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, samples, rays = float(tmax[0]), float(t[1]), float(t[2])
 
+    tile_check = None
+    if tiles and rank == 0:
+        # the gathered film against a rank-local re-render of bands another rank owns (for N = 1: against the same rows
+        # rendered as a plain tile): the per-pixel sums must be bit-identical
+        import numpy as np
+
+        ctx.sync()
+        gathered, _ = ctx.read_film()
+        nbands = (args.height + args.band_rows - 1) // args.band_rows
+        picks = sorted({b for b in (1 % nbands, nbands // 2 | 1, nbands - 1) if b < nbands and (world == 1 or b % world != 0)})
+        ctx.clear_film()
+        for b in picks:
+            y0 = b * args.band_rows
+            for k in range(args.steps):
+                ctx.render_pass(base + (args.warmup + k) * spp, spp, tile=(0, y0, args.width, min(args.band_rows, args.height - y0)))
+        local_film, _ = ctx.read_film()
+        rows = np.concatenate([np.arange(b * args.band_rows, min((b + 1) * args.band_rows, args.height)) for b in picks])
+        tile_check = {"bands_checked": picks, "owners": [b % world for b in picks], "rows": int(len(rows)),
+                      "bit_identical": bool(np.array_equal(gathered[rows], local_film[rows])),
+                      "film_mean": float(gathered.mean())}
+
+    rc = 0
     if rank == 0:
+        expected = args.width * args.height * spp * args.steps * (1 if tiles else world)
         out = {
             "metric": "Mrays/s (room scene, Forward MIS, 1080p)", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
             "samples_per_s": samples / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {
                 "workload": f"room scene stand-in (walls {12 * args.tess * args.tess} triangles, tess={args.tess}), Forward MIS, "
-                            f"{args.width}x{args.height}, max_path_length 10, {spp} spp per step x {args.steps} steps per GPU",
-                "spp_total_per_gpu": spp * args.steps, "rays_per_sample": rays / samples,
-                "parallelism": "single GPU" if world == 1 else f"sample-pass sharding over {world} GPUs + RCCL film reduce",
+                            f"{args.width}x{args.height}, max_path_length 10, {spp} spp per step x {args.steps} steps"
+                            + (" (one job shared by all GPUs)" if tiles else " per GPU"),
+                "spp_total_per_gpu": spp * args.steps, "rays_per_sample": rays / samples, "shard": args.shard,
+                "parallelism": "single GPU" if world == 1 else (
+                    f"tile sharding: bands of {args.band_rows} rows dealt round-robin over {world} GPUs + RCCL film gather" if tiles else
+                    f"sample-pass sharding over {world} GPUs + RCCL film reduce"),
+                "rccl_ranks": dist.get_world_size() if dist is not None else 0,
             },
-            "pipeline_hbm_fraction": rays / elapsed * PIPELINE_BYTES_PER_RAY / (HBM_PEAK_GBS * 1e9),
+            "samples_rendered": samples, "samples_expected": expected,
+            "pipeline_hbm_fraction": rays / elapsed * PIPELINE_BYTES_PER_RAY / (HBM_PEAK_GBS * 1e9 * world),
             "nan_samples": int(c.nan_samples), "stack_overflows": int(c.stack_overflows),
         }
+        if samples != expected:
+            print(f"bench.py: rendered {samples} samples, expected {expected}", file=sys.stderr)
+            rc = 1
+        if tile_check is not None:
+            out["tile_check"] = tile_check
+            if not tile_check["bit_identical"]:
+                print("bench.py: the gathered film differs from the rank-local re-render", file=sys.stderr)
+                rc = 1
+        pmc = None
+        if os.path.exists(PMC_SUMMARY):
+            with open(PMC_SUMMARY) as f:
+                pmc = json.load(f)
         if stages:
             ms, launches = stages["extend"]
             rays_per_launch = c.closest_rays / max(1, launches)
             avg_s = ms * 1e-3 / max(1, launches)
             achieved = EXTEND_BYTES_PER_RAY * rays_per_launch / avg_s / 1e9
+            k = (pmc or {}).get("kernels", {}).get("k_extend", {}) if args.precision == "f32" else {}
             out["roofline"] = {
                 "kernel": "k_extend<float>" if args.precision == "f32" else "k_extend<double>", "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": EXTEND_TRAFFIC_BYTES_PER_RAY * rays_per_launch if args.precision == "f32" else None,
-                "traffic_note": "bytes per launch = 87 B/ray (PMC, profiles/r01_pmc_v14_tcc_*.txt) x rays per launch; the kernel is "
-                                "VALU/latency bound (VALU busy 85 %, TA busy 78 %, lane utilisation 0.57: profiles/r01_pmc_v14_sq.txt), not HBM bound",
+                # fabric bytes per launch from the PMC passes (TCC_EA0_RDREQ x 128 B + WRREQ 64 / 32 B), per ray x this run's rays per launch
+                "traffic": k["fabric_bytes_per_ray"] * rays_per_launch if k.get("fabric_bytes_per_ray") else None,
+                # what actually limits the kernel (PMC): instruction issue under divergence, not bytes
+                "limiter": "valu-issue", "valu_busy": k.get("valu_busy"), "lane_util": k.get("lane_util"), "ta_busy": k.get("ta_busy"),
+                "useful_issue_frac": (k["valu_busy"] * k["lane_util"]) if k.get("valu_busy") and k.get("lane_util") else None,
+                "pmc_source": (pmc or {}).get("source"), "pmc_batch_paths": (pmc or {}).get("batch_paths"),
                 "avg_launch_us": avg_s * 1e6, "launches": int(launches), "rays_per_launch": rays_per_launch,
                 "algorithmic_bytes_per_ray": EXTEND_BYTES_PER_RAY,
-                "stage_ms": {k: v[0] for k, v in stages.items()},
+                "stage_ms": {k2: v[0] for k2, v in stages.items()},
             }
         # VALU side of the roofline. Model flops: 25 per child-box slab test (4 per wide-node step),
         # 60 per primitive test (both counted on the device), 300 per ray for its half of a bounce's shading.
@@ -208,16 +387,25 @@ def main():
             "primitive_tests_per_ray": int(c.reserved[4]) / local_rays,
             "achieved": rays / elapsed * flops_per_ray / 1e12, "peak": VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
             "frac": rays / elapsed * flops_per_ray / 1e12 / (VALU_PEAK_TFLOPS * world),
-            "pmc": "k_extend: VALU busy 85 % of cycles at lane utilisation 0.57; k_shade: VALU busy 41 %, TA busy 71 % (profiles/r01_pmc_v14_sq.txt)",
+            "pmc": {name: {f: v.get(f) for f in ("valu_busy", "lane_util", "ta_busy", "wait_frac", "fabric_bytes_per_ray", "avg_us")}
+                    for name, v in (pmc or {}).get("kernels", {}).items()} if pmc else None,
+            "pmc_source": (pmc or {}).get("source"),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref_rgb, tile, ref_nan = cpu_baseline(S, A, args)
             out["parity"] = parity_gate(ctx, A, args, ref_rgb, tile, ref_nan, out["cpu_baseline"]["kind"])
+            if not out["parity"]["pass"]:
+                print("bench.py: the parity gate FAILED: " + json.dumps(out["parity"]), file=sys.stderr)
+                rc = 1
+    ctx.close()
+    if rank == 0:
+        if world == 1 and not args.no_f64_leg and args.precision == "f32":
+            out["f64"] = f64_leg(R, S, A, args, local)
         print(json.dumps(out), flush=True)
 
-    ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -126,3 +126,18 @@ def test_card_scenes_straddle_the_lds_stack_capacity():
     for n, depth in ((58, 28), (60, 29), (66, 30), (67, 31), (72, 32), (120, 47)):
         assert R.check_scene(cards_scene(n)).max_stack == depth
     assert R.check_scene(ribbon_scene(420)).max_stack > 62
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`bench.py --gpus N` starts N ranks itself; where fewer GPUs are visible (none in the CPU container) it must fail
+    loudly instead of printing a line with n_gpus smaller than asked."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a machine with fewer than two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "refusing" in p.stderr and "metric" not in p.stdout
