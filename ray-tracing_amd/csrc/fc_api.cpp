@@ -320,9 +320,8 @@ namespace
             c->queue_allocs.push_back(p);
             Q.hit_idx[k] = static_cast<uint32_t*>(p);
         }
-        HIP_TRY(c, hipMalloc(&p, sizeof(PathState<R>) * static_cast<size_t>(cap)));
-        c->queue_allocs.push_back(p);
-        Q.state = static_cast<PathState<R>*>(p);
+        for(int k = 0; k < 2; ++k)
+            if((rc = col(&Q.st_c0[k])) || (rc = col(&Q.st_c1[k])) || (rc = col(&Q.st_c2[k]))) return rc;
         Q.counters = c->counters;
         Q.stats = c->stats;
         Q.timeline = nullptr;

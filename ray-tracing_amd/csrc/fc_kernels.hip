@@ -182,6 +182,23 @@ namespace fcg
         return positive ? q + n * rest : q - n * rest;
     }
 
+    // path state columns (Wavefront::st_c*), streamed like the other queue records
+    template<typename R> FC_D PathState<R> state_load(const Wavefront<R>& Q, int set, uint32_t i)
+    {
+        const Vec4<R> a = ld_stream(&Q.st_c0[set][i]), b = ld_stream(&Q.st_c1[set][i]), c = ld_stream(&Q.st_c2[set][i]);
+        PathState<R> st;
+        st.beta[0] = a.x; st.beta[1] = a.y; st.beta[2] = a.z; st.pdf = a.w;
+        st.p1[0] = b.x; st.p1[1] = b.y; st.p1[2] = b.z; st.flags = unpack_word(b.w);
+        st.w[0] = c.x; st.w[1] = c.y; st.w[2] = c.z; st.pad2 = R(0);
+        return st;
+    }
+    template<typename R> FC_D void state_store(const Wavefront<R>& Q, int set, uint32_t i, const PathState<R>& st)
+    {
+        st_stream(&Q.st_c0[set][i], Vec4<R>{st.beta[0], st.beta[1], st.beta[2], st.pdf});
+        st_stream(&Q.st_c1[set][i], Vec4<R>{st.p1[0], st.p1[1], st.p1[2], pack_word(R(0), st.flags)});
+        st_stream(&Q.st_c2[set][i], Vec4<R>{st.w[0], st.w[1], st.w[2], R(0)});
+    }
+
     // ------------------------------------------------------------------ generate
     template<typename R>
     __global__ __launch_bounds__(BLOCK) void k_generate(SceneDev<R> S, Wavefront<R> Q, Batch B)
@@ -219,7 +236,7 @@ namespace fcg
             st.flags = 1u;
             st.p1[0] = origin.x; st.p1[1] = origin.y; st.p1[2] = origin.z;
             st.w[0] = wi.x; st.w[1] = wi.y; st.w[2] = wi.z;
-            Q.state[i] = st;
+            state_store(Q, B.parity, i, st);  // ray i of the first queue
             Q.li_shadow[i] = Vec4<R>{R(0), R(0), R(0), R(0)};
 
             Vec4<R> c0{o.x, o.y, o.z, wi.x};
@@ -735,6 +752,7 @@ namespace fcg
             const uint32_t i = base + threadIdx.x;
             bool emit_ray = false, emit_shadow = false;
             Vec4<R> r0{}, r1{}, s0{}, s1{}, s2{};
+            PathState<R> nst{};  // the state that travels on with the extension ray (written beside it, below)
             if(i < n)
             {
                 const uint32_t hi = hit_idx[i];
@@ -742,7 +760,7 @@ namespace fcg
                 uint32_t hw, path;  // hw = hit_word(kind | index, lobe)
                 unpack_ids(h1, hw, path);
                 uint32_t ms = unpack_word(h1.y);
-                PathState<R> st = Q.state[path];
+                PathState<R> st = state_load(Q, B.parity, hi);
                 vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
                 const vec3<R> p1{st.p1[0], st.p1[1], st.p1[2]};
                 const vec3<R> w12{st.w[0], st.w[1], st.w[2]};  // direction that reached this hit
@@ -922,11 +940,11 @@ namespace fcg
 
                 if(alive)  // a path that ends here leaves nothing behind: what it gathered is in the radiance column
                 {
-                    st.beta[0] = beta.x; st.beta[1] = beta.y; st.beta[2] = beta.z;
-                    st.pdf = pdf_w12;
-                    st.p1[0] = sp.p.x; st.p1[1] = sp.p.y; st.p1[2] = sp.p.z;
-                    st.w[0] = wn.x; st.w[1] = wn.y; st.w[2] = wn.z;
-                    Q.state[path] = st;
+                    nst.beta[0] = beta.x; nst.beta[1] = beta.y; nst.beta[2] = beta.z;
+                    nst.pdf = pdf_w12;
+                    nst.p1[0] = sp.p.x; nst.p1[1] = sp.p.y; nst.p1[2] = sp.p.z;
+                    nst.w[0] = wn.x; nst.w[1] = wn.y; nst.w[2] = wn.z;
+                    nst.flags = st.flags;
                 }
             }
             if constexpr(KEY != Q_FINAL)
@@ -938,6 +956,7 @@ namespace fcg
                 {
                     st_stream(&Q.ray_c0[slot_r], r0);
                     st_stream(&Q.ray_c1[slot_r], r1);
+                    state_store(Q, B.parity ^ 1, slot_r, nst);
                 }
                 if(emit_shadow)
                 {
@@ -957,10 +976,11 @@ namespace fcg
         const bool mis = B.integrator == FCGPU_INTEGRATOR_MIS;
         for(uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
         {
-            Vec4<R> h1 = Q.hit_c1[Q.hit_idx[Q_MISS][i]];
+            const uint32_t hi = Q.hit_idx[Q_MISS][i];
+            Vec4<R> h1 = Q.hit_c1[hi];
             uint32_t prim, path;
             unpack_ids(h1, prim, path);
-            const PathState<R> st = Q.state[path];
+            const PathState<R> st = state_load(Q, B.parity, hi);
             vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
             const vec3<R> w{st.w[0], st.w[1], st.w[2]};  // direction of the ray that left the scene
             vec3<R> env = env_Li(S, w);
