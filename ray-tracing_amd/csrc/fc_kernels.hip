@@ -774,8 +774,13 @@ namespace fcg
                 {
                     const bool entering = dot(ng, w12) <= R(0);
                     const MediumRec<R>& M = S.media[entering ? above : below];
-                    R dist = length(sp.p - p1);
-                    beta = beta * vec3<R>{r_exp(-M.sigma[0] * dist), r_exp(-M.sigma[1] * dist), r_exp(-M.sigma[2] * dist)};  // medium.hpp:47-50
+                    // vacuum_medium (medium.hpp:34-37) and a uniform_medium without density: exp(-0 * d) = 1 exactly, so
+                    // the three exponentials and the distance are only computed inside a medium that absorbs
+                    if(M.sigma[0] != R(0) || M.sigma[1] != R(0) || M.sigma[2] != R(0))
+                    {
+                        R dist = length(sp.p - p1);
+                        beta = beta * vec3<R>{r_exp(-M.sigma[0] * dist), r_exp(-M.sigma[1] * dist), r_exp(-M.sigma[2] * dist)};  // medium.hpp:47-50
+                    }
                 }
                 if(ent.light >= 0)
                 {

@@ -13,14 +13,17 @@ sc = S.room(1920, 1080, tess=tess)
 ctx = Rn.GpuContext(0)
 ctx.set_options(precision=prec, max_paths_in_flight=cap)
 t0 = time.time(); ctx.upload_scene(sc); print("upload", time.time() - t0)
-ctx.render_pass(0, 1); ctx.sync()
 ctx.reset_counters(); ctx.sync()
+ctx.render_pass(0, 1); ctx.sync()
+c0 = ctx.counters()
 t0 = time.time()
 ctx.render_pass(1, spp); ctx.sync()
 dt = time.time() - t0
-c = ctx.counters()
-rays = c.closest_rays + c.shadow_rays
+c = ctx.counters()  # both passes (what a profiler sums over the process); the timed pass is the difference
+rays = c.closest_rays + c.shadow_rays - c0.closest_rays - c0.shadow_rays
 ns = 1920 * 1080 * spp
 print(f"{prec} tess={tess} spp={spp}: {dt:.3f}s  {ns/dt/1e6:.1f} Msamples/s  {rays/dt/1e9:.3f} Grays/s  rays/sample {rays/ns:.2f} launches {c.kernel_launches} overflow {c.stack_overflows}")
 rgb, n = ctx.read_film()
 print("mean", (rgb / n).mean(), "nodes/ray", c.reserved[3]/rays, "prims/ray", c.reserved[4]/rays, "max_stack", c.reserved[1], "wide nodes", c.bvh_nodes)
+import json
+print("RAYS " + json.dumps({"closest_rays": int(c.closest_rays), "shadow_rays": int(c.shadow_rays), "samples": ns + 1920 * 1080}))
