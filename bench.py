@@ -56,7 +56,7 @@ def launch_ranks(args):
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (args.backend == "gloo" and have >= 1):
         print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible: refusing to run fewer ranks than asked", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=176, help="CPU baseline: samples per pixel of the crop on all cores (>= 30 s of work)")
     ap.add_argument("--cpu-1t-spp", type=int, default=4, help="CPU baseline: samples per pixel of the crop on one thread (0 = skip)")
     ap.add_argument("--parity-spp", type=int, default=16, help="samples per pixel the parity gate compares (first leg of the CPU baseline)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI, one GPU per rank (the measured path). gloo = rehearsal of the N-rank logic on a box with fewer "
+                         "GPUs than ranks: ranks share GPUs (local rank modulo the GPUs visible) and the films are reduced through the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64-leg", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stage timing (roofline leg)")
@@ -228,11 +231,15 @@ def main():
         import torch
         import torch.distributed as dist
 
-        if torch.cuda.device_count() <= local:
-            print(f"bench.py: rank {rank} has no GPU {local} ({torch.cuda.device_count()} visible)", file=sys.stderr)
-            sys.exit(2)
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "gloo":
+            local = local % max(1, torch.cuda.device_count())
+            dist.init_process_group("gloo")
+        else:
+            if torch.cuda.device_count() <= local:
+                print(f"bench.py: rank {rank} has no GPU {local} ({torch.cuda.device_count()} visible)", file=sys.stderr)
+                sys.exit(2)
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     S = importlib.import_module("ray-tracing_amd.scenes")
     A = importlib.import_module("ray-tracing_amd._abi")
@@ -244,9 +251,21 @@ def main():
     ctx.upload_scene(scene)
     ctx.set_sampler(0)
     film = None
+    nccl = dist is not None and args.backend == "nccl"
     if dist is not None:
         D = importlib.import_module("ray-tracing_amd.distributed")
+    if nccl:
         film = torch.as_tensor(ctx.film_device_view(), device=torch.device("cuda", local))
+    reduced_host = [None]
+
+    def reduce_films():
+        """per-rank films -> rank 0: in place on the device over RCCL, or (gloo rehearsal) through host copies"""
+        if nccl:
+            D.reduce_film(film, 0, dst=0)
+        else:
+            host = torch.from_numpy(ctx.read_film()[0])
+            D.reduce_film(host, 0, dst=0)
+            reduced_host[0] = host.numpy()
 
     spp = args.spp_per_step
     total_steps = args.warmup + args.steps
@@ -264,17 +283,20 @@ def main():
     def barrier():
         ctx.sync()
         if dist is not None:
-            torch.cuda.synchronize()
+            if nccl:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if nccl:
+                torch.cuda.synchronize()
 
     for w in range(args.warmup):
         render_step(w)
     ctx.sync()
     if dist is not None and args.warmup > 0:
         # warm the collective too: RCCL sets its reduce channels up on first use, which belongs to warm-up
-        D.reduce_film(film, 0, dst=0)
-        torch.cuda.synchronize()
+        reduce_films()
+        if nccl:
+            torch.cuda.synchronize()
     ctx.clear_film()
     ctx.reset_counters()
     if not args.no_profile:
@@ -287,7 +309,7 @@ def main():
         render_step(args.warmup + k)
     if dist is not None:
         ctx.sync()
-        D.reduce_film(film, 0, dst=0)
+        reduce_films()
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -298,7 +320,7 @@ def main():
     rays = c.closest_rays + c.shadow_rays
     samples = local_samples
     if dist is not None:
-        t = torch.tensor([elapsed, float(samples), float(rays)], dtype=torch.float64, device=torch.device("cuda", local))
+        t = torch.tensor([elapsed, float(samples), float(rays)], dtype=torch.float64, device=torch.device("cuda", local) if nccl else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -311,7 +333,7 @@ def main():
         import numpy as np
 
         ctx.sync()
-        gathered, _ = ctx.read_film()
+        gathered = ctx.read_film()[0] if reduced_host[0] is None else reduced_host[0]
         nbands = (args.height + args.band_rows - 1) // args.band_rows
         picks = sorted({b for b in (1 % nbands, nbands // 2 | 1, nbands - 1) if b < nbands and (world == 1 or b % world != 0)})
         ctx.clear_film()
@@ -339,9 +361,10 @@ def main():
                             + (" (one job shared by all GPUs)" if tiles else " per GPU"),
                 "spp_total_per_gpu": spp * args.steps, "rays_per_sample": rays / samples, "shard": args.shard,
                 "parallelism": "single GPU" if world == 1 else (
-                    f"tile sharding: bands of {args.band_rows} rows dealt round-robin over {world} GPUs + RCCL film gather" if tiles else
-                    f"sample-pass sharding over {world} GPUs + RCCL film reduce"),
-                "rccl_ranks": dist.get_world_size() if dist is not None else 0,
+                    f"tile sharding: bands of {args.band_rows} rows dealt round-robin over {world} ranks + film gather" if tiles else
+                    f"sample-pass sharding over {world} ranks + film reduce") + (" (RCCL over xGMI, one GPU per rank)" if nccl else
+                                                                                  " (gloo rehearsal: ranks share GPUs, films reduced through the host)"),
+                "rccl_ranks": dist.get_world_size() if nccl else 0, "backend": args.backend if dist is not None else None,
             },
             "samples_rendered": samples, "samples_expected": expected,
             "pipeline_hbm_fraction": rays / elapsed * PIPELINE_BYTES_PER_RAY / (HBM_PEAK_GBS * 1e9 * world),
