@@ -218,6 +218,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
 
+    # stdout carries the ONE result line and nothing else: whatever libraries print there (RCCL's version banner at the
+    # first communicator, for one) is sent to stderr; the line itself goes to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -424,7 +430,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_f64_leg and args.precision == "f32":
             out["f64"] = f64_leg(R, S, A, args, local)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     if dist is not None:
         dist.destroy_process_group()
