@@ -376,6 +376,24 @@ int fcgpu_bsdf_table(fcgpu_ctx* ctx, const fcgpu_material* material, const doubl
                      const double* ns, const double* bitangent, double eta_a, double eta_b, uint64_t n,
                      const fcgpu_bsdf_query* queries, fcgpu_bsdf_result* results);
 
+/* Parity hook: the discrete decisions of every path of the NEXT render passes, to attribute differences between two
+ * renders of the same samples (fp32 against fp64: tools/divergence.py). No counterpart in the reference. While enabled a
+ * pass must fit one batch; path p of a pass = (sample index within the pass) * pixels + (pixel index within the tile).
+ * hit_words[(h - 1) * paths + p]: what path p hit at its h-th vertex: lobe index (2 bits) | primitive kind (2) | index of
+ * the triangle / sphere / plane record (28), FCGPU_DECISION_MISS when the ray left the scene, FCGPU_DECISION_DEAD when the
+ * path ended without a hit record, 0xFFFFFFFF when it had ended before. flag_words[...]: FCGPU_DECISION_* bits of
+ * what was decided there. fcgpu_read_decision_log returns the sizes (either output pointer may be NULL). */
+#define FCGPU_DECISION_MISS 0xFFFFFFFEu
+#define FCGPU_DECISION_DEAD 0xFFFFFFFDu
+#define FCGPU_DECISION_SHADED 1u        /* the hit was shaded                                             */
+#define FCGPU_DECISION_SAMPLED 2u       /* bsdf->sample_wi succeeded: the path goes on                    */
+#define FCGPU_DECISION_TRANSMITTED 4u   /* the sampled direction crosses the surface                      */
+#define FCGPU_DECISION_SHADOW_CAST 8u   /* the light strategy cast a visibility ray (bsdf->evaluate != 0) */
+#define FCGPU_DECISION_OCCLUDED 16u     /* ... and it was occluded                                        */
+#define FCGPU_DECISION_LOBE_SHIFT 8     /* bits 8..11: lobe type shaded (7 = last vertex)                 */
+int fcgpu_set_decision_log(fcgpu_ctx* ctx, int enabled);
+int fcgpu_read_decision_log(fcgpu_ctx* ctx, uint32_t* bounces, uint64_t* paths, uint32_t* hit_words, uint32_t* flag_words);
+
 /* The no-allocation variant of fcgpu_trace_closest_device. It has NO counterpart in the reference; it exists for callers
  * that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation. Same
  * kernel, same results (bit for bit); the kernel's scratch -- its statistics words and, for hierarchies deeper than the

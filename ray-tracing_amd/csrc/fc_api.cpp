@@ -68,6 +68,10 @@ struct fcgpu_ctx
     uint64_t film_elems{};
     QueueCounters* counters{};
     unsigned long long* stats{};
+    bool decision_log{};               // fcgpu_set_decision_log
+    uint32_t *dec_hit{}, *dec_flags{};  // [dec_bounces][dec_paths], owned (not in a pool: sized per pass)
+    uint32_t dec_bounces{};
+    uint64_t dec_paths{};
     unsigned char* noalloc_scratch{};  // this device's copy of the static scratch array (fc_kernels.hip), set at create
     uint64_t samples{};
     uint64_t launches{};
@@ -334,6 +338,8 @@ namespace
             Q.timeline = static_cast<unsigned long long*>(p);
             c->timeline = Q.timeline;
         }
+        Q.dec_hit = Q.dec_flags = nullptr;
+        Q.dec_stride = 0;
         Q.capacity = cap;
         return FCGPU_OK;
     }
@@ -393,6 +399,25 @@ namespace
         S.offset_along_ray = offset_along_ray(c) ? 1u : 0u;
         const uint64_t P = static_cast<uint64_t>(tile.w) * static_cast<uint64_t>(tile.h);
         const uint64_t cap = Qa.capacity;
+        Wavefront<R> Qlog = Qa;
+        if(c->decision_log)
+        {
+            // parity hook: one word pair per (bounce, path) of THIS pass, which must be one batch so that path ids are unique
+            if(P * sample_count > cap || c->slots > 1) return fail(c, FCGPU_E_LIMIT, "decision log: the pass must fit one batch (and FCGPU_STREAMS=1)");
+            if(c->dec_hit) (void)hipFree(c->dec_hit);
+            if(c->dec_flags) (void)hipFree(c->dec_flags);
+            c->dec_hit = c->dec_flags = nullptr;
+            c->dec_bounces = static_cast<uint32_t>(max_len);
+            c->dec_paths = P * sample_count;
+            const size_t bytes = sizeof(uint32_t) * c->dec_paths * c->dec_bounces;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dec_hit), bytes));
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dec_flags), bytes));
+            HIP_TRY(c, hipMemsetAsync(c->dec_hit, 0xFF, bytes, c->stream));  // 0xFFFFFFFF = the path had ended before
+            HIP_TRY(c, hipMemsetAsync(c->dec_flags, 0, bytes, c->stream));
+            Qlog.dec_hit = c->dec_hit;
+            Qlog.dec_flags = c->dec_flags;
+            Qlog.dec_stride = static_cast<uint32_t>(c->dec_paths);
+        }
         // Two batch slots (FCGPU_STREAMS=2): consecutive batches run on two streams with their own queues,
         // so the memory-bound shade kernels of one batch can share the chip with the VALU-bound traversal
         // of the other. Film adds stay ordered: every accumulate waits for the previous batch's.
@@ -424,7 +449,7 @@ namespace
         auto run_one = [&](uint32_t pix0, uint32_t npix, uint32_t s0, uint32_t nsamp)
         {
             const int slot = c->slots > 1 ? static_cast<int>(batch_index & 1u) : 0;
-            const Wavefront<R>& Q = slot ? Qb : Qa;
+            const Wavefront<R>& Q = slot ? Qb : Qlog;
             LaunchCfg L{slot ? c->stream_b : c->stream, c->grid, c->lds_pad_extend, c->lds_pad_shadow};
             c->span_stream = L.stream;
             // two batches in flight traverse at the same time: each slot has its own spill columns
@@ -732,6 +757,8 @@ extern "C"
         free_pool(c->scene_allocs);
         free_pool(c->queue_allocs);
         if(c->film) (void)hipFree(c->film);
+        if(c->dec_hit) (void)hipFree(c->dec_hit);
+        if(c->dec_flags) (void)hipFree(c->dec_flags);
         (void)hipFree(c->counters);
         if(c->slots > 1)
         {
@@ -938,6 +965,30 @@ extern "C"
         const hipError_t e = hipGetLastError();
         if(e != hipSuccess) return hip_fail(c, e, "trace launch");
         return FCGPU_OK;
+    }
+
+    // ------------------------------------------------------------------ parity hook: per-path decision log
+    int fcgpu_set_decision_log(fcgpu_ctx* c, int enabled)
+    {
+        if(!c) return FCGPU_E_INVALID;
+        c->decision_log = enabled != 0;
+        return FCGPU_OK;
+    }
+
+    int fcgpu_read_decision_log(fcgpu_ctx* c, uint32_t* bounces, uint64_t* paths, uint32_t* hit_words, uint32_t* flag_words)
+    {
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!c->dec_hit) return fail(c, FCGPU_E_INVALID, "no decision log: enable it before the render pass");
+            if(bounces) *bounces = c->dec_bounces;
+            if(paths) *paths = c->dec_paths;
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const size_t bytes = sizeof(uint32_t) * c->dec_paths * c->dec_bounces;
+            if(hit_words) HIP_TRY(c, hipMemcpy(hit_words, c->dec_hit, bytes, hipMemcpyDeviceToHost));
+            if(flag_words) HIP_TRY(c, hipMemcpy(flag_words, c->dec_flags, bytes, hipMemcpyDeviceToHost));
+            return FCGPU_OK;
+        });
     }
 
     // ------------------------------------------------------------------ multi-GPU film reduce (renderer.hpp:125-135)

@@ -352,6 +352,7 @@ namespace fcg
                 {
                     // helper::raycast after scene.raycast returned, integrator.hpp:47-108 (recursion -> re-cast)
                     int key = 0xFF;
+                    uint32_t dec_lobe = 0;
                     Vec4<R> h0{}, h1{};
                     bool recast = false;
                     bool alive = false;
@@ -469,6 +470,7 @@ namespace fcg
                                     key = S.lobes[m.first_lobe + lobe].type;
                                 }
                             }
+                            dec_lobe = lobe;
                             h0 = Vec4<R>{p.x, p.y, p.z, T.b0};
                             h1.x = T.b1;
                             h1.y = pack_word(R(0), ms);
@@ -486,6 +488,8 @@ namespace fcg
                             st_stream(&Q.hit_c1[slot], h1);
                         }
                         Q.hit_key[slot] = static_cast<uint8_t>(key);
+                        if(Q.dec_hit)  // parity hook: what this path hit at vertex h
+                            Q.dec_hit[static_cast<size_t>(B.h - 1) * Q.dec_stride + path] = alive ? hit_word(T.pk, dec_lobe) : (key == Q_MISS ? DEC_MISS : DEC_DEAD);
                         slot = INVALID_U32;
                     }
                 }
@@ -943,6 +947,12 @@ namespace fcg
                     }
                 }
 
+                if(Q.dec_flags)  // parity hook: what was decided at this hit
+                {
+                    uint32_t f = DEC_SHADED | (static_cast<uint32_t>(KEY) << DEC_KEY_SHIFT) | (alive ? DEC_SAMPLED : 0u) | (emit_shadow ? DEC_SHADOW_CAST : 0u);
+                    if(alive && dot(wn, ng) * dot(w12, ng) > R(0)) f |= DEC_TRANSMITTED;  // w12 arrives, wn leaves: same side of ng = went through
+                    Q.dec_flags[static_cast<size_t>(B.h - 1) * Q.dec_stride + path] = f;
+                }
                 if(alive)  // a path that ends here leaves nothing behind: what it gathered is in the radiance column
                 {
                     nst.beta[0] = beta.x; nst.beta[1] = beta.y; nst.beta[2] = beta.z;
@@ -1038,6 +1048,7 @@ namespace fcg
                     if(T.pk != INVALID_U32)
                     {
                         n_occ += 1;
+                        if(Q.dec_flags) Q.dec_flags[static_cast<size_t>(B.h - 1) * Q.dec_stride + path] |= DEC_OCCLUDED;  // this lane holds the path's only shadow ray
                     }
                     else
                     {

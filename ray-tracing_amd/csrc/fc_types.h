@@ -347,6 +347,9 @@ namespace fcg
 
     static_assert(sizeof(PathState<float>) == 48 && sizeof(PathState<double>) == 96, "one path state = three 16-byte (32-byte) pieces");
 
+    constexpr uint32_t DEC_MISS = 0xFFFFFFFEu, DEC_DEAD = 0xFFFFFFFDu;
+    constexpr uint32_t DEC_SHADED = 1u, DEC_SAMPLED = 2u, DEC_TRANSMITTED = 4u, DEC_SHADOW_CAST = 8u, DEC_OCCLUDED = 16u, DEC_KEY_SHIFT = 8u;
+
     constexpr int WORK_RANGES = 8;
 
     struct QueueCounters  // device-resident, zeroed per bounce
@@ -399,6 +402,12 @@ namespace fcg
         // development aid (FCGPU_TIMELINE=file): per wave of the last k_extend launch {start, end (100 MHz
         // ticks), rays, rounds, node steps sum / lane max, primitive tests sum / lane max}; nullptr in normal operation
         unsigned long long* timeline;
+        // parity hook (fcgpu_set_decision_log): per bounce and path, the discrete decisions of the path, or nullptr.
+        // dec_hit[(h - 1) * dec_stride + path] = hit word (lobe | kind | record index) of hit h, DEC_MISS or DEC_DEAD;
+        // dec_flags[...] = DEC_* bits of what k_shade / k_shadow decided at that hit
+        uint32_t* dec_hit;
+        uint32_t* dec_flags;
+        uint32_t dec_stride;
         uint32_t capacity;
     };
 

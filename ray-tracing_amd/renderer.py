@@ -50,6 +50,8 @@ def load_library():
         "fcgpu_trace_closest_device": (i32, [vp, u64, vp, vp]),
         "fcgpu_trace_any_device": (i32, [vp, u64, vp, vp]),
         "fcgpu_trace_closest_noalloc": (i32, [vp, u64, vp, vp]),
+        "fcgpu_set_decision_log": (i32, [vp, i32]),
+        "fcgpu_read_decision_log": (i32, [vp, P(u32), P(u64), vp, vp]),
         "fcgpu_clear_film": (i32, [vp]),
         "fcgpu_read_film": (i32, [vp, vp, P(u64)]),
         "fcgpu_film_device_ptr": (i32, [vp, P(vp), P(u64)]),
@@ -188,6 +190,18 @@ class GpuContext:
 
     def trace_closest_device(self, n, rays_ptr, hits_ptr):
         self._check(self.lib.fcgpu_trace_closest_device(self.h, n, rays_ptr, hits_ptr))
+
+    def set_decision_log(self, enabled):
+        self._check(self.lib.fcgpu_set_decision_log(self.h, int(enabled)))
+
+    def read_decision_log(self):
+        """(hit_words[bounces, paths], flag_words[bounces, paths]) of the last pass rendered with the log enabled."""
+        b, n = C.c_uint32(), C.c_uint64()
+        self._check(self.lib.fcgpu_read_decision_log(self.h, C.byref(b), C.byref(n), None, None))
+        hits = np.zeros((b.value, n.value), np.uint32)
+        flags = np.zeros((b.value, n.value), np.uint32)
+        self._check(self.lib.fcgpu_read_decision_log(self.h, None, None, hits.ctypes.data, flags.ctypes.data))
+        return hits, flags
 
     def trace_closest_noalloc(self, n, rays_ptr, hits_ptr):
         """fcgpu_trace_closest_noalloc: like trace_closest_device, scratch in the library's static device array."""

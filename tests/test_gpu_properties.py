@@ -463,3 +463,41 @@ def test_reduce_film_sums_sample_passes():
     for c in ctxs:
         c.close()
     assert cnt == n and np.allclose(rgb, full, rtol=1e-13, atol=0)
+
+
+def test_decision_log_records_what_the_counters_count():
+    """fcgpu_set_decision_log (parity hook): one hit word and one flag word per vertex and path. Its totals must equal
+    the counters of the same pass (shadow rays cast / occluded, paths that left the scene), it must not change the
+    film, and a second render logs the same words."""
+    sc = S.nested_media(32, 32)
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision="f32")
+        ctx.upload_scene(sc)
+        ctx.set_sampler(4)
+        ctx.render_pass(0, 3)
+        plain, _ = ctx.read_film()
+        ctx.clear_film()
+        ctx.reset_counters()
+        ctx.set_decision_log(True)
+        ctx.render_pass(0, 3)
+        hits, flags = ctx.read_decision_log()
+        logged, _ = ctx.read_film()
+        c = ctx.counters()
+        ctx.clear_film()
+        ctx.render_pass(0, 3)
+        hits2, flags2 = ctx.read_decision_log()
+        with pytest.raises(R.FcgpuError) as e:  # the log needs the pass in one batch
+            ctx.set_options(precision="f32", max_paths_in_flight=256)
+            ctx.render_pass(0, 3)
+        assert e.value.code == A.E_LIMIT
+    assert hits.shape == (10, 32 * 32 * 3)
+    assert np.array_equal(plain, logged)
+    assert np.array_equal(hits, hits2) and np.array_equal(flags, flags2)
+    assert int(((flags & 8) != 0).sum()) == int(c.shadow_rays)
+    assert int(((flags & 16) != 0).sum()) == int(c.shadow_occluded)
+    assert ((flags & 16) == 0)[(flags & 8) == 0].all()          # only a cast ray can be occluded
+    shaded = (flags & 1) != 0
+    assert (hits[shaded] < 0xFFFFFFFD).all()                    # what was shaded had been hit
+    assert (hits[0] != 0xFFFFFFFF).all()                        # every path has a first vertex (hit, miss or dead)
+    went_on = (flags[:-1] & 2) != 0
+    assert (hits[1:][went_on] != 0xFFFFFFFF).all() and (hits[1:][~went_on] == 0xFFFFFFFF).all()
