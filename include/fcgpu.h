@@ -301,6 +301,10 @@ typedef struct fcgpu_ctx fcgpu_ctx;
 
 /* ------------------------------------------------------------------ entry points */
 
+/* GPUs this process can use (fcgpu_create takes 0 .. count - 1): what std::thread::hardware_concurrency() is to the
+ * reference's worker_count (example_scenes.hpp:259). */
+int fcgpu_device_count(int* count);
+
 /* Lifetime. Replaces construction/destruction of fc::renderer (renderer.hpp:23-45). */
 int fcgpu_create(int device, fcgpu_ctx** out);
 int fcgpu_destroy(fcgpu_ctx* ctx);

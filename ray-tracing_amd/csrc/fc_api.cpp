@@ -667,6 +667,19 @@ extern "C"
         }
     }
 
+    int fcgpu_device_count(int* count)
+    {
+        if(!count) return FCGPU_E_INVALID;
+        *count = 0;
+        const hipError_t e = hipGetDeviceCount(count);
+        if(e != hipSuccess)
+        {
+            g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+            return FCGPU_E_HIP;
+        }
+        return FCGPU_OK;
+    }
+
     int fcgpu_create(int device, fcgpu_ctx** out)
     {
         if(!out)

@@ -57,6 +57,15 @@ namespace fcgpu
             check(fcgpu_sync(ctx_));
         }
 
+        // this renderer's share of a frame rendered by several GPUs: the bands of `band_rows` film rows b with
+        // b % band_stride == band_first, all samples, one pass (fcgpu_render_bands); asynchronous, see multi_gpu_renderer
+        void start_bands(std::uint32_t band_rows, std::uint32_t band_first, std::uint32_t band_stride)
+        {
+            check(fcgpu_render_bands(ctx_, band_rows, band_first, band_stride, 0, sample_count_, integrator_.kind, integrator_.max_path_length,
+                                     integrator_.visible_infinity_area_light ? 1 : 0));
+        }
+        void sync() { check(fcgpu_sync(ctx_)); }
+
         // renderer::export_image (renderer.hpp:115-141): `<name>.raw`, float32 RGB, top row first
         void export_image(const std::string& name) { check(fcgpu_export_image(ctx_, name.c_str())); }
 
@@ -87,5 +96,51 @@ namespace fcgpu
         integrator_desc integrator_{};
         std::uint32_t sample_count_{};
         int width_{}, height_{};
+    };
+
+    // fc::renderer with worker_count = number of GPUs (renderer.hpp:65-81: N workers share the frame; :125-135: their films
+    // are summed at export). One context per device in ONE process: every GPU renders its bands of film rows for all
+    // samples (full-width tiles dealt round-robin: each pixel has one owner, so the summed film is bit-identical to one
+    // GPU's), the launches of all GPUs run concurrently, fcgpu_reduce_film sums the films into the first context over xGMI.
+    // `devices` may name a device more than once (two contexts on one GPU: how the one-GPU tests exercise it).
+    class multi_gpu_renderer
+    {
+    public:
+        multi_gpu_renderer(const fcgpu_scene_desc& scene, integrator_desc integrator, std::uint32_t sample_count, const std::vector<int>& devices,
+                           std::uint64_t seed = 0, int precision = FCGPU_PRECISION_F32, bool stratified = false, std::uint32_t band_rows = 4)
+            : band_rows_{band_rows}
+        {
+            if(devices.empty()) throw std::runtime_error("multi_gpu_renderer: no devices");
+            for(int d : devices) parts_.emplace_back(new gpu_renderer(scene, integrator, sample_count, seed, d, precision, stratified));
+        }
+        ~multi_gpu_renderer()
+        {
+            for(gpu_renderer* p : parts_) delete p;
+        }
+        multi_gpu_renderer(const multi_gpu_renderer&) = delete;
+        multi_gpu_renderer& operator=(const multi_gpu_renderer&) = delete;
+
+        void run()
+        {
+            const std::uint32_t n = static_cast<std::uint32_t>(parts_.size());
+            for(std::uint32_t i = 0; i < n; ++i) parts_[i]->start_bands(band_rows_, i, n);  // asynchronous: all GPUs render at once
+            for(gpu_renderer* p : parts_) p->sync();
+            std::vector<fcgpu_ctx*> ctxs;
+            for(gpu_renderer* p : parts_) ctxs.push_back(p->context());
+            const int rc = fcgpu_reduce_film(ctxs.data(), static_cast<int>(ctxs.size()), 0);
+            if(rc != FCGPU_OK) throw std::runtime_error(std::string("fcgpu_reduce_film: ") + fcgpu_last_error(ctxs[0]));
+        }
+        gpu_renderer& root() { return *parts_[0]; }  // holds the whole film after run(): export_image / film / counters
+        void export_image(const std::string& name) { parts_[0]->export_image(name); }
+        std::uint64_t rays()
+        {
+            std::uint64_t n = 0;
+            for(gpu_renderer* p : parts_) n += p->counters().closest_rays + p->counters().shadow_rays;
+            return n;
+        }
+
+    private:
+        std::vector<gpu_renderer*> parts_;
+        std::uint32_t band_rows_;
     };
 }

@@ -50,6 +50,7 @@ def load_library():
         "fcgpu_trace_closest_device": (i32, [vp, u64, vp, vp]),
         "fcgpu_trace_any_device": (i32, [vp, u64, vp, vp]),
         "fcgpu_trace_closest_noalloc": (i32, [vp, u64, vp, vp]),
+        "fcgpu_device_count": (i32, [P(i32)]),
         "fcgpu_set_decision_log": (i32, [vp, i32]),
         "fcgpu_read_decision_log": (i32, [vp, P(u32), P(u64), vp, vp]),
         "fcgpu_clear_film": (i32, [vp]),

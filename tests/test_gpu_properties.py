@@ -230,6 +230,13 @@ def test_cpp_host_renders_the_room_from_asset_files(tmp_path):
     # few paths may flip a discrete decision: compare like the fp32 parity tests do
     err = pixel_rel_err(img.astype(np.float64), ref)
     assert np.mean(err < 1e-3) > 0.97 and abs(img.mean() - ref.mean()) < 0.01 * ref.mean()
+    # the same host with three contexts (fcgpu::multi_gpu_renderer: bands of rows per context, fcgpu_reduce_film): every pixel
+    # has one owner, so the image file is identical byte for byte and the same rays were cast
+    out3 = subprocess.run([exe, str(w), str(h), str(spp), str(tmp_path), "3"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out3.returncode == 0 and "3 contexts" in out3.stdout, out3.stdout + out3.stderr
+    img3 = np.fromfile(tmp_path / "room.raw", dtype=np.float32).reshape(h, w, 3)
+    assert np.array_equal(img, img3)
+    assert out.stdout.split("rays")[1].split()[0] == out3.stdout.split("rays")[1].split()[0]
 
 
 def test_deep_bvh_spills_the_traversal_stack_and_still_matches_the_oracle():
