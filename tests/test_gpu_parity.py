@@ -328,9 +328,10 @@ def test_device_bsdf_tables_f32_within_stated_bounds():
       * picked lobe and delta flag: identical (the pick cdf stays double on the device);
       * sample success flag: differs on at most 1e-3 of the queries (a sampled direction at the horizon, total internal
         reflection decided by the last bit);
-      * ordinary rows: median <= 2e-6, 99.9th percentile <= 2e-3;
+      * ordinary rows: median <= 5e-7, 99.9th percentile <= 2e-4 (measured: <= 1e-7, <= 2e-5);
       * hard rows -- a grazing direction (|cos| = 1e-3, where the smooth GGX lobes' alpha = 4e-6 puts D near 1e10) or
-        the index pairs (1.3614, 1.52) and (1, 1), whose refraction Jacobian cancels --: median <= 1e-5, 99th percentile <= 5e-2."""
+        the index pairs (1.3614, 1.52) and (1, 1), whose refraction Jacobian cancels --: median <= 5e-7, 99th percentile
+        <= 1e-4 (measured 6e-6), worst row <= 0.2 (measured 8e-2: rough glass at grazing incidence)."""
     errs = {f: [] for f in ("f", "pdf", "s_wi", "s_value", "s_pdf")}
     hard = {f: [] for f in errs}
     worst = {f: (0.0, None) for f in errs}
@@ -366,5 +367,5 @@ def test_device_bsdf_tables_f32_within_stated_bounds():
     assert flips <= 1e-3 * total
     for field in errs:
         e, h = np.concatenate(errs[field]), np.concatenate(hard[field])
-        assert np.median(e) <= 2e-6 and np.quantile(e, 0.999) <= 2e-3, field
-        assert np.median(h) <= 1e-5 and np.quantile(h, 0.99) <= 5e-2, field
+        assert np.median(e) <= 5e-7 and np.quantile(e, 0.999) <= 2e-4, field
+        assert np.median(h) <= 5e-7 and np.quantile(h, 0.99) <= 1e-4 and h.max() <= 0.2, field
