@@ -508,3 +508,31 @@ def test_decision_log_records_what_the_counters_count():
     assert (hits[0] != 0xFFFFFFFF).all()                        # every path has a first vertex (hit, miss or dead)
     went_on = (flags[:-1] & 2) != 0
     assert (hits[1:][went_on] != 0xFFFFFFFF).all() and (hits[1:][~went_on] == 0xFFFFFFFF).all()
+
+
+def test_batch_size_is_halved_when_the_device_cannot_hold_the_queues():
+    """With the GPU nearly full (ballast allocated through torch) a pass whose queues do not fit must not fail: the
+    library halves the batch size until they do (fcgpu_options.max_paths_in_flight, FCGPU_E_NOMEM only below 2^16 paths)
+    and renders the same film, bit for bit, in more and smaller batches."""
+    import torch
+
+    sc = S.room(width=1920, height=1080, tess=8)
+    want, n, _ = render(sc, spp=4, cap=1 << 20)  # the reference film, rendered in 1 M-path batches
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision="f32")
+        ctx.upload_scene(sc)
+        ctx.set_sampler(0)
+        torch.cuda.synchronize()
+        free, _total = torch.cuda.mem_get_info(0)
+        keep = 1 << 30  # leave 1 GiB: the 8.3 M-path pass asks for ~2 GiB of queues
+        ballast = torch.empty(max(0, free - keep), dtype=torch.uint8, device="cuda:0")
+        try:
+            ctx.render_pass(0, 4)
+            rgb, m = ctx.read_film()
+            c = ctx.counters()
+        finally:
+            del ballast
+            torch.cuda.empty_cache()
+    assert m == n and c.stack_overflows == 0
+    assert c.kernel_launches >= 2 * 69  # at least two batches' worth of launches (69 each): the pass was split
+    assert np.array_equal(rgb, want)
