@@ -202,7 +202,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--shard", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--band-rows", type=int, default=4, help="tile sharding: rows per band (full-width tiles dealt round-robin)")
-    ap.add_argument("--cpu-spp", type=int, default=176, help="CPU baseline: samples per pixel of the crop on all cores (>= 30 s of work)")
+    ap.add_argument("--cpu-spp", type=int, default=208, help="CPU baseline: samples per pixel of the crop on all cores (>= 30 s of work)")
     ap.add_argument("--cpu-1t-spp", type=int, default=4, help="CPU baseline: samples per pixel of the crop on one thread (0 = skip)")
     ap.add_argument("--parity-spp", type=int, default=16, help="samples per pixel the parity gate compares (first leg of the CPU baseline)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
