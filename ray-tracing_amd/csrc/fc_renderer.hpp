@@ -55,6 +55,14 @@ namespace fcgpu
             check(fcgpu_render_pass(ctx_, tile, 0, sample_count_, integrator_.kind, integrator_.max_path_length,
                                     integrator_.visible_infinity_area_light ? 1 : 0));
             check(fcgpu_sync(ctx_));
+            verify();
+        }
+
+        // a traversal-stack push that found no room means dropped BVH subtrees, i.e. a wrong image: the upload sizes the
+        // stack so that this cannot happen, and a host must not ship the frame if it did
+        void verify()
+        {
+            if(counters().stack_overflows != 0) throw std::runtime_error("fcgpu: traversal stack overflowed (stack_overflows != 0): the image is not valid");
         }
 
         // this renderer's share of a frame rendered by several GPUs: the bands of `band_rows` film rows b with
@@ -124,7 +132,11 @@ namespace fcgpu
         {
             const std::uint32_t n = static_cast<std::uint32_t>(parts_.size());
             for(std::uint32_t i = 0; i < n; ++i) parts_[i]->start_bands(band_rows_, i, n);  // asynchronous: all GPUs render at once
-            for(gpu_renderer* p : parts_) p->sync();
+            for(gpu_renderer* p : parts_)
+            {
+                p->sync();
+                p->verify();
+            }
             std::vector<fcgpu_ctx*> ctxs;
             for(gpu_renderer* p : parts_) ctxs.push_back(p->context());
             const int rc = fcgpu_reduce_film(ctxs.data(), static_cast<int>(ctxs.size()), 0);
