@@ -327,7 +327,7 @@ namespace fcg
         // (forward_bsdf_integrator.hpp:50,56: lobe pick, then u2, u1)
         const uint32_t dim_lobe = 2u + (B.integrator == FCGPU_INTEGRATOR_MIS ? 6u : 3u) * static_cast<uint32_t>(B.h - 1);
 
-        WorkCursor W = work_begin();
+        WorkCursor W = work_begin(n);
         Trav<R> T;
         T.cur = INVALID_U32;
         T.sp = 0;
@@ -1032,7 +1032,7 @@ namespace fcg
         const uint32_t n = Q.counters->shadow[0];
         uint32_t n_cast = 0, n_occ = 0, n_nodes = 0, n_prims = 0;
         StackStats n_overflow;
-        WorkCursor W = work_begin();
+        WorkCursor W = work_begin(n);
         Trav<R> T;
         T.cur = INVALID_U32;
         T.sp = 0;

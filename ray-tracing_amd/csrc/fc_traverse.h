@@ -488,20 +488,31 @@ namespace fcg
     // with its own cursor word; a wave starts in the range of its block (blockIdx & 7: blocks are dealt
     // round-robin to the 8 XCDs, so a range is mostly served by one XCD) and moves on to the next range
     // when its own is exhausted. Idle lanes take ray indices from the wave's current chunk; a new chunk
-    // costs ONE atomic per wave. Small chunks keep the end-of-launch tail short: when the cursors run
-    // dry every wave still has to finish at most WORK_CHUNK rays.
-#ifndef FCG_WORK_CHUNK
-#define FCG_WORK_CHUNK 64
+    // costs ONE atomic per wave. The chunk size follows the queue (work_chunk): large queues are dealt in
+    // chunks of 512 consecutive rays, which a wave then works through on its own -- measured at 132 M rays per
+    // launch against chunks of 64: k_extend -2.7 %, k_shadow -5 % (neighbours in the queue were emitted by
+    // neighbouring shade threads and, for shadow rays, all aim at the lights) --; small queues keep chunks of 64
+    // so that the end-of-launch tail stays short: when the cursors run dry every wave still has to finish at most one chunk.
+#ifndef FCG_WORK_CHUNK_MIN
+#define FCG_WORK_CHUNK_MIN 64
 #endif
-    constexpr uint32_t WORK_CHUNK = FCG_WORK_CHUNK;
+#ifndef FCG_WORK_CHUNK_MAX
+#define FCG_WORK_CHUNK_MAX 512
+#endif
+    FC_D uint32_t work_chunk(uint32_t n)
+    {
+        const uint32_t c = n >> 16;  // ~1/8 of a wave's fair share of a queue served by 8192 waves
+        return c < FCG_WORK_CHUNK_MIN ? FCG_WORK_CHUNK_MIN : (c > FCG_WORK_CHUNK_MAX ? FCG_WORK_CHUNK_MAX : c);
+    }
 
     struct WorkCursor
     {
         uint32_t cur, end;     // wave-uniform: rest of the current chunk
         uint32_t range, tried; // current range; ranges found exhausted (WORK_RANGES = nothing left)
+        uint32_t chunk;        // rays per chunk for this launch (work_chunk)
     };
 
-    FC_D WorkCursor work_begin() { return WorkCursor{0u, 0u, blockIdx.x & (WORK_RANGES - 1), 0u}; }
+    FC_D WorkCursor work_begin(uint32_t n) { return WorkCursor{0u, 0u, blockIdx.x & (WORK_RANGES - 1), 0u, work_chunk(n)}; }
     FC_D uint32_t work_range_lo(uint32_t n, uint32_t r) { return static_cast<uint32_t>((static_cast<uint64_t>(n) * r) / WORK_RANGES); }
 
     // returns this lane's new ray index or INVALID_U32; `want` = lane is idle
@@ -518,7 +529,7 @@ namespace fcg
                 if(W.tried >= static_cast<uint32_t>(WORK_RANGES)) break;
                 const uint32_t lo = work_range_lo(n, W.range), hi = work_range_lo(n, W.range + 1u);
                 uint32_t base = 0;
-                if((threadIdx.x & 63) == 0) base = atomicAdd(&counters[W.range][0], WORK_CHUNK);
+                if((threadIdx.x & 63) == 0) base = atomicAdd(&counters[W.range][0], W.chunk);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if(base >= hi - lo)
                 {
@@ -527,7 +538,7 @@ namespace fcg
                     continue;
                 }
                 W.cur = lo + base;
-                W.end = hi - W.cur < WORK_CHUNK ? hi : W.cur + WORK_CHUNK;
+                W.end = hi - W.cur < W.chunk ? hi : W.cur + W.chunk;
             }
             uint32_t avail = W.end - W.cur;
             uint32_t rank = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
