@@ -331,7 +331,7 @@ namespace
         Q.timeline = nullptr;
         if(std::getenv("FCGPU_TIMELINE"))
         {
-            c->timeline_words = static_cast<size_t>(c->grid) * 4u * 16u;
+            c->timeline_words = static_cast<size_t>(c->grid) * 4u * TIMELINE_WORDS;
             HIP_TRY(c, hipMalloc(&p, sizeof(unsigned long long) * c->timeline_words));
             c->queue_allocs.push_back(p);
             HIP_TRY(c, hipMemset(p, 0, sizeof(unsigned long long) * c->timeline_words));

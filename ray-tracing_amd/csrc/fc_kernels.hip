@@ -314,7 +314,9 @@ namespace fcg
     template<typename R, bool PROF, bool SPILL, bool TEX>
     __global__ __launch_bounds__(BLOCK) void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
-        unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};  // PROF: descent, leaf cycles, trips, leaf phases, finish cycles, finish phases
+        // PROF: descent, leaf cycles, trips, leaf phases, finish cycles, finish phases, leaf lanes, finish lanes, cycles of the finish phase's
+        // three parts (hit record, work_take, ray load + set-up)
+        unsigned long long ph[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
         __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
         uint32_t* stack = stack_lds + threadIdx.x;
@@ -347,7 +349,11 @@ namespace fcg
             if(__popcll(__ballot(finished)) >= B.finish_min || any_trav == 0ull)
             {
                 unsigned long long cf = 0;
-                if(PROF) cf = clock64();
+                if(PROF)
+                {
+                    cf = clock64();
+                    ph[7] += __popcll(__ballot(finished));
+                }
                 if(finished)
                 {
                     // helper::raycast after scene.raycast returned, integrator.hpp:47-108 (recursion -> re-cast)
@@ -494,7 +500,10 @@ namespace fcg
                     }
                 }
                 // idle lanes take new rays
+                unsigned long long c1 = 0, c2 = 0;
+                if(PROF) c1 = clock64();
                 uint32_t fresh = work_take(W, slot == INVALID_U32, Q.counters->work_extend, n);
+                if(PROF) c2 = clock64();
                 if(fresh != INVALID_U32)
                 {
                     slot = fresh;
@@ -508,8 +517,12 @@ namespace fcg
                 if(__ballot(slot != INVALID_U32) == 0ull) break;
                 if(PROF)
                 {
-                    ph[4] += clock64() - cf;
+                    const unsigned long long c3 = clock64();
+                    ph[4] += c3 - cf;
                     ph[5] += 1;
+                    ph[8] += c1 - cf;
+                    ph[9] += c2 - c1;
+                    ph[10] += c3 - c2;
                 }
             }
             trav_round<R, false, BLOCK, SPILL, PROF>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims, ph);
@@ -529,7 +542,7 @@ namespace fcg
             }
             if((threadIdx.x & 63) == 0)
             {
-                unsigned long long* t = Q.timeline + (static_cast<size_t>(blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 16u;
+                unsigned long long* t = Q.timeline + (static_cast<size_t>(blockIdx.x) * WAVES + (threadIdx.x >> 6)) * TIMELINE_WORDS;
                 t[0] = t_start;
                 t[1] = wall_clock64();
                 t[2] = rays;
@@ -538,7 +551,7 @@ namespace fcg
                 t[5] = nodes_max;
                 t[6] = prims;
                 t[7] = prims_max;
-                for(int k = 0; k < 6; ++k) t[8 + k] = ph[k];
+                for(int k = 0; k < 11; ++k) t[8 + k] = ph[k];
             }
         }
         wave_stat_add(Q.stats, ST_CLOSEST, n_cast);
@@ -920,18 +933,8 @@ namespace fcg
                     draw(B, key, dim_u2, u2x, u2y);
                     draw(B, key, dim_u1, u1x, u1y);
                     vec3<R> value;
-#ifdef FCG_DEBUG_PRINT
-                    printf("shade key %d h %d path %u hw %08x textured %d p %.9g %.9g %.9g b %.9g %.9g | L type %d fr %d c %.6g %.6g %.6g c2 %.6g %.6g %.6g a %.6g %.6g ior %.6g fac %.6g | eta %.6g %.6g u1 %.9g %.9g u2 %.9g %.9g w10 %.9g %.9g %.9g\n",
-                           KEY, B.h, path, hw, mat.textured, (double)sp.p.x, (double)sp.p.y, (double)sp.p.z, (double)h0.w, (double)h1.x, L.type, L.fresnel,
-                           (double)L.color[0], (double)L.color[1], (double)L.color[2], (double)L.color2[0], (double)L.color2[1], (double)L.color2[2],
-                           (double)L.alpha[0], (double)L.alpha[1], (double)L.ior, (double)L.factor, (double)eta_a, (double)eta_b, (double)u1x, (double)u1y,
-                           (double)u2x, (double)u2y, (double)w10.x, (double)w10.y, (double)w10.z);
-#endif
                     if(bsdf_sample_wi<KEY, NM>(L, sp.f, w10, eta_a, eta_b, u1x, u1y, u2x, u2y, wn, value, pdf_w12, &nmap))
                     {
-#ifdef FCG_DEBUG_PRINT
-                        printf("   -> wn %.9g %.9g %.9g value %.6g %.6g %.6g pdf %.6g\n", (double)wn.x, (double)wn.y, (double)wn.z, (double)value.x, (double)value.y, (double)value.z, (double)pdf_w12);
-#endif
                         beta = beta * (value * (r_abs(dot(ng, wn)) / pdf_w12));  // :112
                         alive = true;
                         // helper::raycast entry: leaving p into its own medium pushes it, integrator.hpp:36-44

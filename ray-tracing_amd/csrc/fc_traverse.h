@@ -371,7 +371,7 @@ namespace fcg
     // NODEBUF_WAVE-byte LDS staging area. All 64 lanes of the wave must call it together.
 
     // PROF (development aid): ph[0] += clock cycles in the descent loop, ph[1] += cycles in the leaf
-    // phase, ph[2] += wave-level descent trips, ph[3] += leaf phases entered.
+    // phase, ph[2] += wave-level descent trips, ph[3] += leaf phases entered, ph[6] += lanes holding a leaf in them.
     template<typename R, bool ANY, int STRIDE, bool SPILL, bool PROF = false>
     FC_D void trav_round(const SceneDev<R>& S, Trav<R>& T, uint32_t* stack, unsigned char* nodebuf, StackStats& overflow, int descend_min,
                          uint32_t& n_nodes, uint32_t& n_prims, unsigned long long* ph = nullptr)
@@ -410,7 +410,9 @@ namespace fcg
         {
             c1 = clock64();
             ph[0] += c1 - c0;
-            ph[3] += __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull ? 1 : 0;
+            const uint64_t lm = __ballot(child_is_leaf(cur) && cur != INVALID_U32);
+            ph[3] += lm != 0ull ? 1 : 0;
+            ph[6] += __popcll(lm);
         }
         if(child_is_leaf(cur) && cur != INVALID_U32)
         {

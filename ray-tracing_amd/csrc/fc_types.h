@@ -15,6 +15,8 @@
 
 namespace fcg
 {
+    constexpr int TIMELINE_WORDS = 24;  // per wave, FCGPU_TIMELINE development aid (k_extend's PROF instantiation)
+
     constexpr uint32_t INVALID_U32 = 0xFFFFFFFFu;
 
     // ---- BVH
@@ -401,7 +403,7 @@ namespace fcg
         unsigned long long* stats;
         // development aid (FCGPU_TIMELINE=file): per wave of the last k_extend launch {start, end (100 MHz
         // ticks), rays, rounds, node steps sum / lane max, primitive tests sum / lane max}; nullptr in normal operation
-        unsigned long long* timeline;
+        unsigned long long* timeline;  // FCGPU_TIMELINE: TIMELINE_WORDS words per wave of the grid
         // parity hook (fcgpu_set_decision_log): per bounce and path, the discrete decisions of the path, or nullptr.
         // dec_hit[(h - 1) * dec_stride + path] = hit word (lobe | kind | record index) of hit h, DEC_MISS or DEC_DEAD;
         // dec_flags[...] = DEC_* bits of what k_shade / k_shadow decided at that hit
