@@ -400,6 +400,17 @@ namespace fcg
 #endif
                 uint32_t next = node_step<R, ANY, STRIDE, SPILL>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, sp, overflow);
                 n_nodes += 1;
+                if(PROF && next == INVALID_U32)
+                {
+                    // steps that found nothing: ph[11]; of those, the ones a shrunken t_max emptied (a stack entry pushed
+                    // before the hit was found: what keeping entry distances on the stack could skip): ph[12]
+                    ph[11] += 1;
+                    int sp2 = sp;
+                    StackStats dummy;
+                    if(!SPILL && sp <= STACK_CAP - 3 &&
+                       node_step<R, ANY, STRIDE, SPILL>(T.rc, consts<R>::inf, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, sp2, dummy) != INVALID_U32)
+                        ph[12] += 1;
+                }
                 if(next == INVALID_U32 && sp > 0) next = stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp);
                 cur = next;
             }
