@@ -76,6 +76,7 @@ struct fcgpu_ctx
     uint64_t samples{};
     uint64_t launches{};
     int grid{};
+    int stream_grid{};  // grid of the streaming kernels (LaunchCfg::stream_grid)
     unsigned long long* timeline{};  // FCGPU_TIMELINE development aid
     size_t timeline_words{};
     int lds_pad_extend{0}, lds_pad_shadow{0};  // FCGPU_LDS_PAD_EXTEND / _SHADOW (bytes)
@@ -450,7 +451,7 @@ namespace
         {
             const int slot = c->slots > 1 ? static_cast<int>(batch_index & 1u) : 0;
             const Wavefront<R>& Q = slot ? Qb : Qlog;
-            LaunchCfg L{slot ? c->stream_b : c->stream, c->grid, c->lds_pad_extend, c->lds_pad_shadow};
+            LaunchCfg L{slot ? c->stream_b : c->stream, c->grid, c->lds_pad_extend, c->lds_pad_shadow, c->stream_grid};
             c->span_stream = L.stream;
             // two batches in flight traverse at the same time: each slot has its own spill columns
             if(c->stack_spill) S.stack_spill = c->stack_spill + static_cast<size_t>(slot) * c->stack_spill_words;
@@ -723,6 +724,10 @@ extern "C"
         hipDeviceProp_t prop{};
         if((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
         c->grid = std::max(1, prop.multiProcessorCount) * 8;
+        // the grid-stride streaming kernels run 128 blocks per CU: blocks that come and go keep loads and stores of many
+        // trips in flight at once (a plain column copy of the queues' shape streams 4.4 TB/s from 8 blocks per CU and
+        // 5.05 TB/s from 128, tools/micro/stream_bw.hip; k_shade -3.5 %, k_generate -25 %)
+        c->stream_grid = std::max(1, prop.multiProcessorCount) * 128;
         if(const char* e = std::getenv("FCGPU_LDS_PAD_EXTEND")) c->lds_pad_extend = std::max(0, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_LDS_PAD_SHADOW")) c->lds_pad_shadow = std::max(0, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_FINISH_MIN")) c->finish_min = std::max(1, std::atoi(e));
@@ -730,6 +735,7 @@ extern "C"
         if(const char* e = std::getenv("FCGPU_FINISH_MIN_SHADOW")) c->finish_min_shadow = std::max(1, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_DESCEND_MIN_SHADOW")) c->descend_min_shadow = std::max(0, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_GRID_MULT")) c->grid = std::max(1, prop.multiProcessorCount) * std::max(1, std::atoi(e));
+        if(const char* e = std::getenv("FCGPU_STREAM_GRID_MULT")) c->stream_grid = std::max(1, prop.multiProcessorCount) * std::max(1, std::atoi(e));
         if(const char* e = std::getenv("FCGPU_STREAMS")) c->slots = std::atoi(e) >= 2 ? 2 : 1;
         if(c->slots > 1)
         {

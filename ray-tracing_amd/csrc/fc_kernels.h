@@ -37,6 +37,8 @@ namespace fcg
         hipStream_t stream;
         int grid;       // persistent grid size (blocks of 256)
         int lds_pad_extend = 0, lds_pad_shadow = 0;  // extra dynamic LDS per block: caps the blocks per CU (tuning)
+        int stream_grid = 0;  // grid of the grid-stride streaming kernels (generate, shade, miss, accumulate); 0 = `grid`
+        int streaming() const { return stream_grid > 0 ? stream_grid : grid; }
     };
 
     // fc_lbvh.hip: binary hierarchy over primitive bounds ([n][6]) built on the device (Morton sort + Karras tree + bounds)

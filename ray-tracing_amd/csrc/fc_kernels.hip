@@ -182,15 +182,18 @@ namespace fcg
         return positive ? q + n * rest : q - n * rest;
     }
 
-    // path state columns (Wavefront::st_c*), streamed like the other queue records
-    template<typename R> FC_D PathState<R> state_load(const Wavefront<R>& Q, int set, uint32_t i)
+    template<typename R> FC_D PathState<R> state_unpack(const Vec4<R>& a, const Vec4<R>& b, const Vec4<R>& c)
     {
-        const Vec4<R> a = ld_stream(&Q.st_c0[set][i]), b = ld_stream(&Q.st_c1[set][i]), c = ld_stream(&Q.st_c2[set][i]);
         PathState<R> st;
         st.beta[0] = a.x; st.beta[1] = a.y; st.beta[2] = a.z; st.pdf = a.w;
         st.p1[0] = b.x; st.p1[1] = b.y; st.p1[2] = b.z; st.flags = unpack_word(b.w);
         st.w[0] = c.x; st.w[1] = c.y; st.w[2] = c.z; st.pad2 = R(0);
         return st;
+    }
+    // path state columns (Wavefront::st_c*), streamed like the other queue records
+    template<typename R> FC_D PathState<R> state_load(const Wavefront<R>& Q, int set, uint32_t i)
+    {
+        return state_unpack(ld_stream(&Q.st_c0[set][i]), ld_stream(&Q.st_c1[set][i]), ld_stream(&Q.st_c2[set][i]));
     }
     template<typename R> FC_D void state_store(const Wavefront<R>& Q, int set, uint32_t i, const PathState<R>& st)
     {
@@ -766,20 +769,39 @@ namespace fcg
         const uint32_t dim_u2 = dim + (mis ? 4u : 1u), dim_u1 = dim + (mis ? 5u : 2u);
         const uint32_t* hit_idx = Q.hit_idx[KEY];
 
-        for(uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK)
+        // Software pipeline over the trips of the grid-stride loop. A trip's critical path used to be three memory round
+        // trips in a row (the acknowledgement of the previous trip's stores, its index hit_idx[i], then the records at that
+        // index) before the first gather of the shading itself could start. The records of trip k + 1 (and the index of trip
+        // k + 2) are now requested at the end of trip k, after the queue append and before the stores: few values are
+        // live there, so the 21 registers in flight do not add to the kernel's peak, and the loads share their wait
+        // with the stores' instead of following it.
+        const uint32_t stride = gridDim.x * BLOCK;
+        uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+        Vec4<R> nx_h0{}, nx_h1{}, nx_s0{}, nx_s1{}, nx_s2{};  // records of the coming trip
+        uint32_t hi_next = 0;                                  // index of the trip after it
+        if(i < n)
         {
-            const uint32_t i = base + threadIdx.x;
+            const uint32_t hi = hit_idx[i];
+            nx_h0 = ld_stream(&Q.hit_c0[hi]);
+            nx_h1 = ld_stream(&Q.hit_c1[hi]);
+            nx_s0 = ld_stream(&Q.st_c0[B.parity][hi]);
+            nx_s1 = ld_stream(&Q.st_c1[B.parity][hi]);
+            nx_s2 = ld_stream_xyz(&Q.st_c2[B.parity][hi]);
+        }
+        if(static_cast<uint64_t>(i) + stride < n) hi_next = hit_idx[i + stride];  // else 0: a valid record that is dropped
+
+        for(uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, i += stride)
+        {
             bool emit_ray = false, emit_shadow = false;
             Vec4<R> r0{}, r1{}, s0{}, s1{}, s2{};
             PathState<R> nst{};  // the state that travels on with the extension ray (written beside it, below)
             if(i < n)
             {
-                const uint32_t hi = hit_idx[i];
-                Vec4<R> h0 = ld_stream(&Q.hit_c0[hi]), h1 = ld_stream(&Q.hit_c1[hi]);
+                const Vec4<R> h0 = nx_h0, h1 = nx_h1;
                 uint32_t hw, path;  // hw = hit_word(kind | index, lobe)
                 unpack_ids(h1, hw, path);
                 uint32_t ms = unpack_word(h1.y);
-                PathState<R> st = state_load(Q, B.parity, hi);
+                PathState<R> st = state_unpack(nx_s0, nx_s1, nx_s2);
                 vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
                 const vec3<R> p1{st.p1[0], st.p1[1], st.p1[2]};
                 const vec3<R> w12{st.w[0], st.w[1], st.w[2]};  // direction that reached this hit
@@ -967,11 +989,23 @@ namespace fcg
                     nst.flags = st.flags;
                 }
             }
+            uint32_t slot_r = 0, slot_s = 0;
+            // two independent appends share one pass: queue 0 = extension rays, queue 1 = shadow rays
+            if constexpr(KEY != Q_FINAL) block_append2(emit_ray, emit_shadow, q_ctr, q_lds, slot_r, slot_s);
+            {
+                // the coming trip's records and the index of the one after it (see the top of the loop)
+                // unconditional (a trip past the end re-reads record 0 and drops it): a conditional request would keep
+                // the old values alive through the whole trip
+                const uint64_t i2 = static_cast<uint64_t>(i) + stride + stride;
+                nx_h0 = ld_stream(&Q.hit_c0[hi_next]);
+                nx_h1 = ld_stream(&Q.hit_c1[hi_next]);
+                nx_s0 = ld_stream(&Q.st_c0[B.parity][hi_next]);
+                nx_s1 = ld_stream(&Q.st_c1[B.parity][hi_next]);
+                nx_s2 = ld_stream_xyz(&Q.st_c2[B.parity][hi_next]);
+                hi_next = hit_idx[i2 < n ? static_cast<uint32_t>(i2) : 0u];
+            }
             if constexpr(KEY != Q_FINAL)
             {
-                // two independent appends share one pass: queue 0 = extension rays, queue 1 = shadow rays
-                uint32_t slot_r, slot_s;
-                block_append2(emit_ray, emit_shadow, q_ctr, q_lds, slot_r, slot_s);
                 if(emit_ray)
                 {
                     st_stream(&Q.ray_c0[slot_r], r0);
@@ -1310,7 +1344,7 @@ namespace fcg
     // ------------------------------------------------------------------ launchers
     template<typename R> void launch_generate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
-        hipLaunchKernelGGL(k_generate<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
+        hipLaunchKernelGGL(k_generate<R>, dim3(L.streaming()), dim3(BLOCK), 0, L.stream, S, Q, B);
     }
     template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
@@ -1337,7 +1371,7 @@ namespace fcg
     }
     template<typename R, bool TEX> void launch_shade_lobe(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key)
     {
-        const dim3 g(L.grid), b(BLOCK);
+        const dim3 g(L.streaming()), b(BLOCK);
         switch(key)
         {
         case L_LAMBERT: hipLaunchKernelGGL((k_shade<R, L_LAMBERT, TEX>), g, b, 0, L.stream, S, Q, B); break;
@@ -1352,7 +1386,7 @@ namespace fcg
     }
     template<typename R> void launch_shade(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, int key)
     {
-        const dim3 g(L.grid), b(BLOCK);
+        const dim3 g(L.streaming()), b(BLOCK);
         if(key == Q_FINAL)
             hipLaunchKernelGGL((k_shade<R, Q_FINAL, false>), g, b, 0, L.stream, S, Q, B);  // arrival terms only: no lobe is built
         else if(key == Q_MISS)
@@ -1371,7 +1405,7 @@ namespace fcg
     }
     template<typename R> void launch_accumulate(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
-        hipLaunchKernelGGL(k_accumulate<R>, dim3(L.grid), dim3(BLOCK), 0, L.stream, S, Q, B);
+        hipLaunchKernelGGL(k_accumulate<R>, dim3(L.streaming()), dim3(BLOCK), 0, L.stream, S, Q, B);
     }
 #ifndef FCG_ONLY_F64
     void launch_reset_counters(const LaunchCfg& L, QueueCounters* c, int parity_to_keep)

@@ -438,6 +438,20 @@ namespace fcg
         return *p;
 #endif
     }
+    // x, y, z of a Vec4 column whose w is unused (w reads as 0): for a load that stays in flight across other work, so that
+    // no register of it is dead on arrival (the compiler hands a dead destination register to the next instruction that
+    // needs one, and that instruction then waits for the whole load)
+    template<typename R> struct stream_xyz { typedef R type __attribute__((ext_vector_type(3))); };
+    template<typename R> FC_D Vec4<R> ld_stream_xyz(const Vec4<R>* p)
+    {
+        typedef typename stream_xyz<R>::type V;
+#if FCG_STREAM_HINTS
+        const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+#else
+        const V v = *reinterpret_cast<const V*>(p);
+#endif
+        return Vec4<R>{v.x, v.y, v.z, R(0)};
+    }
     template<typename T> FC_D void st_stream(T* p, const T& v)
     {
         static_assert(sizeof(T) % 16 == 0, "whole 16-byte pieces");
