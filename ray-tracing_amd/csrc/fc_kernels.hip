@@ -597,6 +597,7 @@ namespace fcg
 #pragma unroll
             for(int k = 0; k < Q_COUNT; ++k)
             {
+                if(Q.hit_idx[k] == nullptr) continue;  // a key this scene cannot produce (no such lobe, no environment) has no list
                 uint32_t run = 0;
 #pragma unroll
                 for(int j = 0; j < SORT_ITEMS; ++j)
