@@ -318,8 +318,9 @@ namespace fcg
     __global__ __launch_bounds__(BLOCK) void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         // PROF: descent, leaf cycles, trips, leaf phases, finish cycles, finish phases, leaf lanes, finish lanes, cycles of the finish phase's
-        // three parts (hit record, work_take, ray load + set-up), per-lane node steps that found nothing, of those emptied by t_max
-        unsigned long long ph[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // three parts (hit record, work_take, ray load + set-up), per-lane node steps that found nothing, of those emptied by t_max,
+        // lanes waiting with a leaf / with a finished ray summed over the descent trips
+        unsigned long long ph[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
         __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
         uint32_t* stack = stack_lds + threadIdx.x;
@@ -556,7 +557,7 @@ namespace fcg
                 t[5] = nodes_max;
                 t[6] = prims;
                 t[7] = prims_max;
-                for(int k = 0; k < 13; ++k) t[8 + k] = ph[k];
+                for(int k = 0; k < 15; ++k) t[8 + k] = ph[k];
             }
         }
         wave_stat_add(Q.stats, ST_CLOSEST, n_cast);

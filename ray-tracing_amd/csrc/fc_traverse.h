@@ -387,7 +387,12 @@ namespace fcg
             const bool descending = !child_is_leaf(cur);
             const uint64_t dm = __ballot(descending);
             if(dm == 0ull || (leaf_waiting && __popcll(dm) < descend_min)) break;
-            if(PROF) ph[2] += 1;
+            if(PROF)
+            {
+                ph[2] += 1;
+                ph[13] += __popcll(__ballot(child_is_leaf(cur) && cur != INVALID_U32));  // lanes waiting with a leaf through this trip
+                ph[14] += __popcll(__ballot(cur == INVALID_U32));                        // lanes with a finished ray (or none)
+            }
 #if FCG_COOP_FETCH
             coop_fetch_nodes(S.nodes, cur, nodebuf);
 #endif

@@ -25,7 +25,7 @@ late = w & (end > np.percentile(end[w], 90))
 early = w & (end < np.percentile(end[w], 10))
 for name, m in (("latest 10%", late), ("earliest 10%", early)):
     print(f"{name}: rays {rays[m].mean():.0f} rounds {rounds[m].mean():.1f} nodes-sum {nodes[m].mean():.0f} nodes-lane-max {nmax[m].mean():.0f} life {life[m].mean():.1f}")
-ph = t[:, 8:21].astype(float)
+ph = t[:, 8:23].astype(float)
 tot = ph[w][:, [0, 1, 4]].sum(1)
 print("shader-clock cycles per wave: descent %.0f (%.0f%%)  leaf %.0f (%.0f%%)  finish+fetch %.0f (%.0f%%)" % (
     ph[w, 0].mean(), 100 * (ph[w, 0] / tot).mean(), ph[w, 1].mean(), 100 * (ph[w, 1] / tot).mean(), ph[w, 4].mean(), 100 * (ph[w, 4] / tot).mean()))
@@ -38,3 +38,5 @@ print("lane efficiency: descent %.3f (node steps / 64 x trips)  leaf %.3f  finis
 print("finish phase parts, cycles each: hit record %.0f  work_take %.0f  ray load + set-up %.0f" % tuple((ph[w, k] / np.maximum(ph[w, 5], 1)).mean() for k in (8, 9, 10)))
 print("node steps that found nothing: %.3f of all steps; emptied only by the shrunken t_max: %.3f" % (
     ph[w, 11].sum() / nodes[w].sum(), ph[w, 12].sum() / nodes[w].sum()))
+print("lanes per descent trip: descending %.1f  waiting with a leaf %.1f  finished / empty %.1f" % (
+    nodes[w].sum() / ph[w, 2].sum(), ph[w, 13].sum() / ph[w, 2].sum(), ph[w, 14].sum() / ph[w, 2].sum()))
