@@ -84,11 +84,33 @@ template<bool TILED> void rung(const char* name, const u4* s, u4* d, size_t n, i
     float ms; hipEventElapsedTime(&ms, a, b); ms /= 5;
     printf("%-34s grid %5d: %7.3f ms  %6.2f TB/s\n", name, grid, ms, 16.0 * n * 13 / ms / 1e9);
 }
+// plain columns, column c shifted by c * skew records (does the relative alignment of the columns matter?)
+__global__ __launch_bounds__(256) void ks(const u4* __restrict__ src, u4* __restrict__ dst, size_t n, size_t skew)
+{
+    for(size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull)
+    {
+        u4 acc{1u, 2u, 3u, 4u};
+#pragma unroll
+        for(int c = 0; c < 5; ++c) acc += __builtin_nontemporal_load(src + c * (n + skew) + i);
+#pragma unroll
+        for(int c = 0; c < 8; ++c) __builtin_nontemporal_store(acc + (unsigned)c, dst + c * (n + skew) + i);
+    }
+}
+void runs(const u4* s, u4* d, size_t n, int grid, size_t skew)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(ks, dim3(grid), dim3(256), 0, 0, s, d, n, skew);
+    hipEventRecord(a);
+    for(int r = 0; r < 5; ++r) hipLaunchKernelGGL(ks, dim3(grid), dim3(256), 0, 0, s, d, n, skew);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= 5;
+    printf("k_shade mix, columns skewed by %7zu B      grid %5d: %7.3f ms  %6.2f TB/s\n", skew * 16, grid, ms, 16.0 * n * 13 / ms / 1e9);
+}
 int main()
 {
-    const size_t n = 1ull << 27;  // records per column: 2 GiB per column
+    const size_t n = (1ull << 27) - (1ull << 20);  // leaves room for the skewed variant inside the same allocations  // records per column: 2 GiB per column
     u4 *s, *d;
-    if(hipMalloc(&s, 16 * n * 6) != hipSuccess || hipMalloc(&d, 16 * n * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    if(hipMalloc(&s, 16 * (n + (1ull << 20)) * 6) != hipSuccess || hipMalloc(&d, 16 * (n + (1ull << 20)) * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(s, 1, 16 * n * 6); hipMemset(d, 0, 16 * n * 8);
     for(int grid : {2048, 8192, 32768})
     {
@@ -105,6 +127,7 @@ int main()
         run<5, 0, true, true>("read only, nt, tiles", s, d, n, grid);
         rung<false>("k_shade groups {2,3}->{2,3,3} cols", s, d, n, grid);
         rung<true>("k_shade groups {2,3}->{2,3,3} tiled", s, d, n, grid);
+        for(size_t skew : {0ull, 8ull, 16ull, 64ull, 256ull, 1024ull, 4096ull, 16384ull + 16ull, 65536ull + 4096ull + 64ull}) runs(s, d, n, grid, skew);
     }
     return 0;
 }
