@@ -106,11 +106,64 @@ void runs(const u4* s, u4* d, size_t n, int grid, size_t skew)
     float ms; hipEventElapsedTime(&ms, a, b); ms /= 5;
     printf("k_shade mix, columns skewed by %7zu B      grid %5d: %7.3f ms  %6.2f TB/s\n", skew * 16, grid, ms, 16.0 * n * 13 / ms / 1e9);
 }
+// k_shade's mix with its queue append: the 8 output columns are written at slots a block obtains with one atomic per
+// output queue and trip (two queues: columns 0-4 and 5-7), as block_append2 does; ATOMIC = false writes at the
+// record's own index (k_generate's pattern). Every record appends, so the slots stay below n.
+template<bool ATOMIC>
+__global__ __launch_bounds__(256) void ka(const u4* __restrict__ src, u4* __restrict__ dst, size_t n, unsigned* ctr)
+{
+    __shared__ unsigned base_lds[2];
+    for(size_t i0 = blockIdx.x * 256ull; i0 < n; i0 += gridDim.x * 256ull)
+    {
+        const size_t i = i0 + threadIdx.x;
+        u4 acc{1u, 2u, 3u, 4u};
+        if(i < n)
+        {
+#pragma unroll
+            for(int c = 0; c < 5; ++c) acc += __builtin_nontemporal_load(src + c * n + i);
+        }
+        size_t slot_a = i, slot_b = i;
+        if(ATOMIC)
+        {
+            const unsigned count = static_cast<unsigned>(n - i0 < 256 ? n - i0 : 256);
+            __syncthreads();
+            if(threadIdx.x < 2) base_lds[threadIdx.x] = atomicAdd(&ctr[threadIdx.x * 32], count);
+            __syncthreads();
+            slot_a = base_lds[0] + threadIdx.x;
+            slot_b = base_lds[1] + threadIdx.x;
+            __syncthreads();
+        }
+        if(i < n)
+        {
+#pragma unroll
+            for(int c = 0; c < 5; ++c) __builtin_nontemporal_store(acc + (unsigned)c, dst + c * n + slot_a);
+#pragma unroll
+            for(int c = 5; c < 8; ++c) __builtin_nontemporal_store(acc + (unsigned)c, dst + c * n + slot_b);
+        }
+    }
+}
+template<bool ATOMIC> void runa(const char* name, const u4* s, u4* d, size_t n, int grid, unsigned* ctr)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float total = 0;
+    for(int r = 0; r < 6; ++r)
+    {
+        hipMemsetAsync(ctr, 0, 256, 0);  // the slots restart at 0 for every launch: all of them stay below n
+        hipEventRecord(a);
+        hipLaunchKernelGGL((ka<ATOMIC>), dim3(grid), dim3(256), 0, 0, s, d, n, ctr);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if(r > 0) total += ms;
+    }
+    const float ms = total / 5;
+    printf("%-34s grid %5d: %7.3f ms  %6.2f TB/s  (%.0f atomics/us per counter)\n", name, grid, ms, 16.0 * n * 13 / ms / 1e9, ATOMIC ? (n / 256.0) / (ms * 1e3) : 0.0);
+}
 int main()
 {
     const size_t n = (1ull << 27) - (1ull << 20);  // leaves room for the skewed variant inside the same allocations  // records per column: 2 GiB per column
     u4 *s, *d;
     if(hipMalloc(&s, 16 * (n + (1ull << 20)) * 6) != hipSuccess || hipMalloc(&d, 16 * (n + (1ull << 20)) * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    unsigned* ctr; hipMalloc(&ctr, 256);
     hipMemset(s, 1, 16 * n * 6); hipMemset(d, 0, 16 * n * 8);
     for(int grid : {2048, 8192, 32768})
     {
@@ -127,6 +180,8 @@ int main()
         run<5, 0, true, true>("read only, nt, tiles", s, d, n, grid);
         rung<false>("k_shade groups {2,3}->{2,3,3} cols", s, d, n, grid);
         rung<true>("k_shade groups {2,3}->{2,3,3} tiled", s, d, n, grid);
+        runa<false>("k_shade mix, own index", s, d, n, grid, ctr);
+        runa<true>("k_shade mix, block-atomic append", s, d, n, grid, ctr);
         for(size_t skew : {0ull, 8ull, 16ull, 64ull, 256ull, 1024ull, 4096ull, 16384ull + 16ull, 65536ull + 4096ull + 64ull}) runs(s, d, n, grid, skew);
     }
     return 0;
