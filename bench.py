@@ -399,8 +399,10 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 # fabric bytes per launch from the PMC passes (TCC_EA0_RDREQ x 128 B + WRREQ 64 / 32 B), per ray x this run's rays per launch
                 "traffic": k["fabric_bytes_per_ray"] * rays_per_launch if k.get("fabric_bytes_per_ray") else None,
-                # what actually limits the kernel (PMC): instruction issue under divergence, not bytes
-                "limiter": "valu-issue", "valu_busy": k.get("valu_busy"), "lane_util": k.get("lane_util"), "ta_busy": k.get("ta_busy"),
+                # what actually limits the kernel, not bytes: the L1 address path (four 16-byte requests per lane and node
+                # step; one request more costs 5.4 %, nine VALU instructions fewer cost nothing: DESIGN.md section 5) beside
+                # instruction issue under divergence (the PMC fractions that follow)
+                "limiter": "l1-requests+valu-issue", "valu_busy": k.get("valu_busy"), "lane_util": k.get("lane_util"), "ta_busy": k.get("ta_busy"),
                 "useful_issue_frac": (k["valu_busy"] * k["lane_util"]) if k.get("valu_busy") and k.get("lane_util") else None,
                 "pmc_source": (pmc or {}).get("source"), "pmc_batch_paths": (pmc or {}).get("batch_paths"),
                 "avg_launch_us": avg_s * 1e6, "launches": int(launches), "rays_per_launch": rays_per_launch,

@@ -683,7 +683,6 @@ namespace fcg
                         deepest = std::max(deepest, emit(std::move(sub)));
                     }
                 }
-                node.n = static_cast<uint8_t>(kids.size());
                 out_.nodes[index] = node;
                 // while one child is being traversed at most (n - 1) siblings wait on the stack
                 return static_cast<uint32_t>(kids.size() - 1) + deepest;
@@ -696,7 +695,7 @@ namespace fcg
                 node.ox = box.lo[0];
                 node.oy = box.lo[1];
                 node.oz = box.lo[2];
-                uint8_t* ebytes[3]{&node.ex, &node.ey, &node.ez};
+                float* steps[3]{&node.sx, &node.sy, &node.sz};
                 for(int a = 0; a < 3; ++a)
                 {
                     float extent = box.hi[a] - box.lo[a];
@@ -735,7 +734,7 @@ namespace fcg
                         {
                             node.qlo[a] = lo_word;
                             node.qhi[a] = hi_word;
-                            *ebytes[a] = static_cast<uint8_t>(e + 127);
+                            *steps[a] = step;  // 2^e, e >= -120: a normal float
                             break;
                         }
                         ++e;

@@ -134,6 +134,12 @@ namespace fcg
         if((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[index], static_cast<unsigned long long>(v));
     }
 
+    // v is already a per-wave total held by every lane
+    FC_D void wave_stat_add_uniform(unsigned long long* stats, int index, uint32_t v)
+    {
+        if((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[index], static_cast<unsigned long long>(v));
+    }
+
     template<typename R> FC_D uint32_t medium_top(const SceneDev<R>& S, uint32_t ms)  // integrator.hpp:51-56
     {
         uint32_t top = 0;
@@ -561,10 +567,11 @@ namespace fcg
             }
         }
         wave_stat_add(Q.stats, ST_CLOSEST, n_cast);
-        wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost);
+        // per-lane counts are summed over the wave; the counts trav_round keeps per wave (fc_traverse.h) are added once
+        if(SPILL) wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost); else wave_stat_add_uniform(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost);
         wave_stat_add(Q.stats, ST_STACK_SPILL, n_overflow.spilled);
         wave_stat_add(Q.stats, ST_MEDIUM_OVERFLOW, n_moverflow);
-        wave_stat_add(Q.stats, ST_NODES, n_nodes);
+        if(PROF) wave_stat_add(Q.stats, ST_NODES, n_nodes); else wave_stat_add_uniform(Q.stats, ST_NODES, n_nodes);
         wave_stat_add(Q.stats, ST_PRIMS, n_prims);
     }
 
@@ -1118,9 +1125,9 @@ namespace fcg
         }
         wave_stat_add(Q.stats, ST_SHADOW, n_cast);
         wave_stat_add(Q.stats, ST_OCCLUDED, n_occ);
-        wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost);
+        if(SPILL) wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost); else wave_stat_add_uniform(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost);
         wave_stat_add(Q.stats, ST_STACK_SPILL, n_overflow.spilled);
-        wave_stat_add(Q.stats, ST_NODES, n_nodes);
+        wave_stat_add_uniform(Q.stats, ST_NODES, n_nodes);
         wave_stat_add(Q.stats, ST_PRIMS, n_prims);
     }
 
@@ -1223,7 +1230,7 @@ namespace fcg
                 if(active) occluded[i] = hit ? 1 : 0;
             }
         }
-        wave_stat_add(stats, ST_STACK_OVERFLOW, n_overflow.lost);
+        if(SPILL) wave_stat_add(stats, ST_STACK_OVERFLOW, n_overflow.lost); else wave_stat_add_uniform(stats, ST_STACK_OVERFLOW, n_overflow.lost);
         wave_stat_add(stats, ST_STACK_SPILL, n_overflow.spilled);
     }
 

@@ -133,13 +133,6 @@ namespace fcg
         return true;
     }
 
-    template<typename R> FC_D R exp2_from_biased(uint32_t e);
-    template<> FC_D float exp2_from_biased<float>(uint32_t e) { return __builtin_bit_cast(float, e << 23); }
-    template<> FC_D double exp2_from_biased<double>(uint32_t e)
-    {
-        return __builtin_bit_cast(double, static_cast<uint64_t>(e + (1023u - 127u)) << 52);
-    }
-
     FC_D uint32_t order_key(float t) { return __builtin_bit_cast(uint32_t, t); }  // t >= 0: bit order == value order
     FC_D uint32_t order_key(double t) { return order_key(static_cast<float>(t)); }
 
@@ -157,6 +150,8 @@ namespace fcg
 
     struct StackStats
     {
+        // SPILL kernels: per lane. Non-SPILL kernels: `lost` is a per-WAVE count held by every lane (node_step), which
+        // stat_add_lost() below adds once per wave.
         uint32_t lost{0};     // pushes beyond every capacity: a wrong image, must stay 0 (the host sizes the spill area)
         uint32_t spilled{0};  // pushes that went to the global spill area
     };
@@ -216,12 +211,12 @@ namespace fcg
     // is what min/max of the two plane distances would give.
     template<typename R, bool ANY, int STRIDE, bool SPILL>
     FC_D uint32_t node_step(const RayCtx<R>& rc, R t_max, uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint32_t* stack, uint32_t* spill,
-                            uint32_t spill_stride, int& sp, StackStats& overflow)
+                            uint32_t spill_stride, int& sp, StackStats& overflow, bool& lost_push)
     {
         R ox = R(__builtin_bit_cast(float, n0.x)), oy = R(__builtin_bit_cast(float, n0.y)), oz = R(__builtin_bit_cast(float, n0.z));
-        R ax = exp2_from_biased<R>(n0.w & 0xFFu) * rc.inv_d.x;
-        R ay = exp2_from_biased<R>((n0.w >> 8) & 0xFFu) * rc.inv_d.y;
-        R az = exp2_from_biased<R>((n0.w >> 16) & 0xFFu) * rc.inv_d.z;
+        R ax = R(__builtin_bit_cast(float, n0.w)) * rc.inv_d.x;  // grid steps: powers of two (Node4::sx, sy, sz)
+        R ay = R(__builtin_bit_cast(float, n2.z)) * rc.inv_d.y;
+        R az = R(__builtin_bit_cast(float, n2.w)) * rc.inv_d.z;
         R bx = (ox - rc.o.x) * rc.inv_d.x, by = (oy - rc.o.y) * rc.inv_d.y, bz = (oz - rc.o.z) * rc.inv_d.z;
         uint32_t qnx = rc.negx ? n1.w : n1.x, qfx = rc.negx ? n1.x : n1.w;
         uint32_t qny = rc.negy ? n2.x : n1.y, qfy = rc.negy ? n1.y : n2.x;
@@ -249,8 +244,10 @@ namespace fcg
             // one test per step instead of one per push: exact while the BVH's worst case is <= STACK_CAP - 2 entries (a step
             // that has anything to push then starts at sp <= STACK_CAP - 3); the upload gives every deeper hierarchy,
             // also one that would just fit, the SPILL instantiation, so `room` is always true here
+            // a lost push (cannot happen, see above) is reported as a predicate: the caller counts it per wave on the
+            // scalar unit (the ballot of a comparison is its mask), which costs the vector unit nothing
             const bool room = sp <= STACK_CAP - 3;
-            overflow.lost += (!room && key[1] != INVALID_U32) ? 1u : 0u;
+            lost_push = !room && key[1] != INVALID_U32;
 #pragma unroll
             for(int k = 3; k >= 1; --k)
             {
@@ -370,6 +367,8 @@ namespace fcg
     // `stack` points at this lane's column: entry k is stack[k * STRIDE]; `nodebuf` is the wave's
     // NODEBUF_WAVE-byte LDS staging area. All 64 lanes of the wave must call it together.
 
+    // n_nodes: PROF: this lane's node steps; otherwise the WAVE's node steps, the same value in every lane (add it once
+    // per wave: wave_stat_add_uniform). n_prims: this lane's primitive tests.
     // PROF (development aid): ph[0] += clock cycles in the descent loop, ph[1] += cycles in the leaf
     // phase, ph[2] += wave-level descent trips, ph[3] += leaf phases entered, ph[6] += lanes holding a leaf in them.
     template<typename R, bool ANY, int STRIDE, bool SPILL, bool PROF = false>
@@ -396,6 +395,7 @@ namespace fcg
 #if FCG_COOP_FETCH
             coop_fetch_nodes(S.nodes, cur, nodebuf);
 #endif
+            bool lost_push = false;
             if(descending)
             {
 #if FCG_COOP_FETCH
@@ -403,8 +403,8 @@ namespace fcg
 #else
                 const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
 #endif
-                uint32_t next = node_step<R, ANY, STRIDE, SPILL>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, sp, overflow);
-                n_nodes += 1;
+                uint32_t next = node_step<R, ANY, STRIDE, SPILL>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, sp, overflow, lost_push);
+                if(PROF) n_nodes += 1;  // per lane (the timeline wants the lane maximum); otherwise per wave, below
                 if(PROF && next == INVALID_U32)
                 {
                     // steps that found nothing: ph[11]; of those, the ones a shrunken t_max emptied (a stack entry pushed
@@ -412,13 +412,16 @@ namespace fcg
                     ph[11] += 1;
                     int sp2 = sp;
                     StackStats dummy;
+                    bool dummy_lost = false;
                     if(!SPILL && sp <= STACK_CAP - 3 &&
-                       node_step<R, ANY, STRIDE, SPILL>(T.rc, consts<R>::inf, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, sp2, dummy) != INVALID_U32)
+                       node_step<R, ANY, STRIDE, SPILL>(T.rc, consts<R>::inf, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, sp2, dummy, dummy_lost) != INVALID_U32)
                         ph[12] += 1;
                 }
                 if(next == INVALID_U32 && sp > 0) next = stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp);
                 cur = next;
             }
+            if(!PROF) n_nodes += __popcll(dm);  // node steps of the whole wave, counted on the scalar unit
+            if(!SPILL) overflow.lost += __popcll(__ballot(lost_push));
             leaf_waiting = leaf_waiting || __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
         }
         unsigned long long c1 = 0;

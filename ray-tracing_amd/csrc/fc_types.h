@@ -38,10 +38,10 @@ namespace fcg
     struct alignas(16) Node4
     {
         float ox, oy, oz;       // grid origin (= node box minimum)
-        uint8_t ex, ey, ez, n;  // biased fp32 exponents of the grid step per axis; n = child count
+        float sx;               // grid step along x: a power of two, stored as the float the node step multiplies with
         uint32_t qlo[3];        // per axis: byte c = quantised lower bound of child c
         uint32_t qhi[3];        // per axis: byte c = quantised upper bound of child c
-        uint32_t pad[2];
+        float sy, sz;           // grid steps along y and z (kept as floats, not exponent bytes: six instructions fewer per node step)
         uint32_t child[4];      // interior: node index; leaf: NODE_LEAF_BIT | kind<<29 | (count-1)<<26 | first; empty: INVALID_U32
     };
     static_assert(sizeof(Node4) == 64, "Node4 must be one 64-byte line");

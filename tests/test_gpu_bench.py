@@ -31,7 +31,7 @@ def test_bench_line_single_gpu_tiles():
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["unit"] == "Mrays/s" and d["value"] > 0
     assert d["samples_rendered"] == d["samples_expected"] == 480 * 270 * 4 * 2
     assert d["tile_check"]["bit_identical"] and d["tile_check"]["rows"] > 0
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["limiter"] == "valu-issue"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["limiter"] == "l1-requests+valu-issue"
     assert d["stack_overflows"] == 0 and d["nan_samples"] == 0
 
 
