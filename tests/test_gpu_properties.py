@@ -33,6 +33,21 @@ def test_deterministic_and_batching_invariant():
     assert np.array_equal(a, d)
 
 
+def test_film_does_not_depend_on_the_streaming_grid(monkeypatch):
+    """k_generate / k_shade / k_miss / k_accumulate are grid-stride loops (k_shade software-pipelined over its trips: the
+    records of the next trip are requested during the current one). With one block per CU the 172 800 paths of this pass
+    take three trips of the whole grid (256 CUs) where the default 128 blocks per CU take one: same film, same ray counts,
+    bit for bit, in both precisions."""
+    sc = S.room(width=320, height=180, tess=16)
+    for precision in ("f32", "f64"):
+        monkeypatch.delenv("FCGPU_STREAM_GRID_MULT", raising=False)
+        a, n, ca = render(sc, precision=precision, spp=3)
+        monkeypatch.setenv("FCGPU_STREAM_GRID_MULT", "1")  # read at fcgpu_create
+        b, m, cb = render(sc, precision=precision, spp=3)
+        assert n == m and np.array_equal(a, b)
+        assert (ca.closest_rays, ca.shadow_rays, ca.nan_samples) == (cb.closest_rays, cb.shadow_rays, cb.nan_samples)
+
+
 def test_tile_sharding_is_bit_exact():
     sc = S.room(width=256, height=144, tess=8)
     full, n, _ = render(sc, spp=2)
