@@ -151,7 +151,7 @@ def parity_gate(ctx, A, args, ref_rgb, tile, ref_nan, kind):
         "median_rel_err": float(np.median(rel)), "fraction_within_1e-2": float((rel <= 1e-2).mean()),
         "fraction_within_1e-3": float((rel <= 1e-3).mean()),
         "mean_ratio": float(a.mean() / b.mean()), "rel_mse": mse,
-        "nan_samples": [int(c.nan_samples), ref_nan], "stack_overflows": int(c.stack_overflows),
+        "nan_samples": [int(c.nan_samples), ref_nan], "stack_overflows": int(c.stack_overflows), "medium_overflows": int(c.medium_overflows),
     }
     f64 = args.precision == "f64"
     th = {
@@ -162,7 +162,7 @@ def parity_gate(ctx, A, args, ref_rgb, tile, ref_nan, kind):
     out["thresholds"] = th
     out["pass"] = bool(out["median_rel_err"] <= th["median_rel_err_max"] and out["fraction_within_1e-2"] >= th["fraction_within_1e-2_min"]
                        and abs(out["mean_ratio"] - 1.0) <= th["mean_ratio_tol"] and mse <= th["rel_mse_max"]
-                       and out["nan_samples"][0] == out["nan_samples"][1] and out["stack_overflows"] == 0)
+                       and out["nan_samples"][0] == out["nan_samples"][1] and out["stack_overflows"] == 0 and out["medium_overflows"] == 0)
     return out
 
 
@@ -374,8 +374,11 @@ def main():
             },
             "samples_rendered": samples, "samples_expected": expected,
             "pipeline_hbm_fraction": rays / elapsed * PIPELINE_BYTES_PER_RAY / (HBM_PEAK_GBS * 1e9 * world),
-            "nan_samples": int(c.nan_samples), "stack_overflows": int(c.stack_overflows),
+            "nan_samples": int(c.nan_samples), "stack_overflows": int(c.stack_overflows), "medium_overflows": int(c.medium_overflows),
         }
+        if c.stack_overflows or c.medium_overflows:
+            print("bench.py: dropped traversal-stack or medium-stack pushes: the frames are not valid", file=sys.stderr)
+            rc = 1
         if samples != expected:
             print(f"bench.py: rendered {samples} samples, expected {expected}", file=sys.stderr)
             rc = 1

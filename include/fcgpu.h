@@ -280,6 +280,11 @@ typedef struct fcgpu_counters {
                                    [2] binary BVH nodes, [3] node steps, [4] primitive tests, [5] traversal-stack
                                    pushes spilled to global memory (deep BVHs only), [6] microseconds the last
                                    fcgpu_upload_scene spent flattening the scene incl. the BVH build */
+    uint64_t medium_overflows;  /* pushes onto a path's priority-medium stack beyond the reference's capacity (the vacuum
+                                   + 9 nested media, integrator.hpp:24, where the reference writes past its array). The
+                                   push is dropped, so the image is not valid: must stay 0 like stack_overflows
+                                   (also in reserved[0])                                                          */
+    uint64_t medium_deep_pushes;/* diagnostics: pushes that landed in entries 6..9 of that stack                  */
 } fcgpu_counters;
 
 /* per-stage device time, measured with HIP events on the context's stream around each launch

@@ -29,6 +29,9 @@ FILMS = [
     ("nested_smooth", "nested_media", dict(width=40, height=40, smooth=True), 4, 10),
     ("nested_rough", "nested_media", dict(width=40, height=40, smooth=False), 4, 10),
     ("nested_noenv", "nested_media", dict(width=32, height=32, smooth=True, env=None), 4, 10),
+    # nine concentric media, alternately hidden and refracting: paths reach the helper's full capacity (integrator.hpp:24)
+    ("nested_deep9", "nested_deep", dict(width=40, height=40, depth=9), 4, 24),
+    ("nested_deep9_rough", "nested_deep", dict(width=32, height=32, depth=9, smooth=False), 4, 24),
     # texture_infinity_area_light over image textures of the four pixel formats, thin-lens camera
     ("envtex_rgb32", "env_texture_scene", dict(width=48, height=32), 4, 10),
     ("envtex_srgb8_box", "env_texture_scene", dict(width=40, height=28, fmt="srgb8", filter="box", emitter=True), 4, 10),
@@ -57,6 +60,22 @@ FILMS_STRATIFIED = [
     ("room_t4_strat9", "room", dict(width=64, height=36, tess=4), 9, 10, 9),
     ("zoo_strat16_epoch", "primitives_zoo", dict(width=40, height=40), 20, 10, 16),
     ("mask_strat16", "mask_scene", dict(width=32, height=48, detail=16, texture_size=16), 16, 10, 16),
+]
+
+
+# Crops of the BASELINE configurations at full size: (name, builder, kwargs, tile (x0, y0, w, h), spp, max_path_length).
+#   headline       configs[1]: room, Forward MIS, 1920x1080, the bench's tess 64 (centre sphere = rough glass), centre 240 x 135
+#   c3_*           configs[2]: the same frame with the other centre materials of the sweep (delta mirror, delta glass with its
+#                  medium, the two-lobe plastic)
+#   c4_mask        configs[3]: mask_scene at the size tools/configs_3_to_5.sh benches it (detail 256 = 255 520 triangles, four 1024^2
+#                  maps, thin lens, texture environment) at 3840x2160; the crop crosses the mask's silhouette and an eye opening
+_CENTRE_1080P = ((1920 - 240) // 2, (1080 - 135) // 2, 240, 135)
+CROPS = [
+    ("headline", "room", dict(width=1920, height=1080, tess=64), _CENTRE_1080P, 16, 10),
+    ("c3_smooth_mirror", "room", dict(width=1920, height=1080, tess=64, center="smooth_mirror"), _CENTRE_1080P, 16, 10),
+    ("c3_smooth_glass", "room", dict(width=1920, height=1080, tess=64, center="smooth_glass"), _CENTRE_1080P, 16, 10),
+    ("c3_plastic", "room", dict(width=1920, height=1080, tess=64, center="plastic"), _CENTRE_1080P, 16, 10),
+    ("c4_mask", "mask_scene", dict(width=3840, height=2160, detail=256, texture_size=1024), (1320, 540, 240, 135), 8, 10),
 ]
 
 
@@ -111,18 +130,18 @@ def main():
         print("film", name, {k: float(v.mean()) for k, v in out.items() if k.endswith("rgb_sum")})
         rs.close()
 
-    # the headline configuration itself (BASELINE.json configs[1]: room, Forward MIS, 1920x1080, the bench's tess 64): the centre
-    # 240 x 135 pixels of the full frame at 16 spp, seed 0 = the sample streams bench.py renders. Only the crop is stored.
-    if wanted("crop_headline"):
-        kw = dict(width=1920, height=1080, tess=64)
-        tile = ((1920 - 240) // 2, (1080 - 135) // 2, 240, 135)
-        rs = ref.scene(S.room(**kw))
-        rgb, n, st = rs.render(16, integrator=A.INTEGRATOR_MIS, max_path_length=10, threads=8, seed=0, tile=tile)
+    # the BASELINE configurations AT THE SIZE THEY RUN (a defect can hide on a thumbnail: round 1's fp32 origin offset did):
+    # a crop of the full frame, seed 0 = the sample streams bench.py renders. Only the crop is stored.
+    for name, builder, kw, tile, spp, mpl in CROPS:
+        if not wanted("crop_" + name):
+            continue
+        rs = ref.scene(S.BUILDERS[builder](**kw))
+        rgb, n, st = rs.render(spp, integrator=A.INTEGRATOR_MIS, max_path_length=mpl, threads=8, seed=0, tile=tile)
         x0, y0, w, h = tile
-        np.savez_compressed(os.path.join(OUT, "crop_headline.npz"), builder="room", kwargs=repr(kw), spp=16, max_path_length=10, seed=0,
+        np.savez_compressed(os.path.join(OUT, f"crop_{name}.npz"), builder=builder, kwargs=repr(kw), spp=spp, max_path_length=mpl, seed=0,
                             tile=np.array(tile), mis_rgb_sum=rgb[y0:y0 + h, x0:x0 + w], mis_count=np.uint64(n),
                             mis_rays=np.array([st.closest_rays, st.any_rays, st.any_occluded, st.nan_samples], np.uint64), **meta)
-        print("crop headline", float(rgb.mean()), n)
+        print("crop", name, float(rgb[y0:y0 + h, x0:x0 + w].mean()), n, "rays", st.closest_rays, st.any_rays)
         rs.close()
 
     # ray / hit sets: the rays the reference itself casts (natural distribution) + uniform random rays

@@ -217,11 +217,17 @@ def reference_decode_image(raw, fmt):
     return out
 
 
-def reference_load_image(root, name):
+def reference_load_image(root, name, compiler="g++"):
     """fc::assets::get_image on <root>/assets/images/<name>; returns None when the reference's loader
-    rejects the file -- which the g++ build always does (see fcref_load_image in ref_harness.cpp)."""
-    lib = reference().lib
-    f = lib.fcref_load_image
+    rejects the file -- which the g++ build always does (see fcref_load_image in ref_harness.cpp), and the
+    clang++ build of the loader (compiler="clang++": oracle/ref_assets_clang.cpp) as well."""
+    if compiler == "clang++":
+        path = os.path.join(_HERE, "_ref", "libfcref_assets_clang.so")
+        if not os.path.exists(path):
+            return None
+        f = C.CDLL(path).fcref_clang_load_image
+    else:
+        f = reference().lib.fcref_load_image
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
     w, h = C.c_int(), C.c_int()

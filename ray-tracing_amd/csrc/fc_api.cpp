@@ -412,7 +412,12 @@ namespace
             c->dec_paths = P * sample_count;
             const size_t bytes = sizeof(uint32_t) * c->dec_paths * c->dec_bounces;
             HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dec_hit), bytes));
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dec_flags), bytes));
+            if(const hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&c->dec_flags), bytes); e2 != hipSuccess)
+            {
+                (void)hipFree(c->dec_hit);  // both or none: fcgpu_read_decision_log tests dec_hit
+                c->dec_hit = c->dec_flags = nullptr;
+                return hip_fail(c, e2, "hipMalloc(decision log)");
+            }
             HIP_TRY(c, hipMemsetAsync(c->dec_hit, 0xFF, bytes, c->stream));  // 0xFFFFFFFF = the path had ended before
             HIP_TRY(c, hipMemsetAsync(c->dec_flags, 0, bytes, c->stream));
             Qlog.dec_hit = c->dec_hit;
@@ -627,7 +632,7 @@ namespace
 
 extern "C"
 {
-    int fcgpu_version(void) { return 1003; }
+    int fcgpu_version(void) { return 1004; }
 
     int fcgpu_check_scene(const fcgpu_scene_desc* d, uint32_t bvh_builder, fcgpu_scene_stats* out)
     {
@@ -1196,6 +1201,8 @@ extern "C"
             out->reserved[4] = st[ST_PRIMS];
             out->reserved[5] = st[ST_STACK_SPILL];
             out->reserved[6] = c->flatten_us;
+            out->medium_overflows = st[ST_MEDIUM_OVERFLOW];
+            out->medium_deep_pushes = st[ST_MEDIUM_DEEP];
             return FCGPU_OK;
         });
     }

@@ -140,11 +140,11 @@ namespace fcg
         if((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[index], static_cast<unsigned long long>(v));
     }
 
-    template<typename R> FC_D uint32_t medium_top(const SceneDev<R>& S, uint32_t ms)  // integrator.hpp:51-56
+    template<typename R> FC_D uint32_t medium_top(const SceneDev<R>& S, const MStack& ms)  // integrator.hpp:51-56
     {
         uint32_t top = 0;
         int top_prio = S.media[0].priority;
-        uint32_t n = ms_count(ms);
+        uint32_t n = ms_count(ms.w);
         for(uint32_t i = 0; i < n; ++i)
         {
             uint32_t id = ms_get(ms, i);
@@ -158,16 +158,20 @@ namespace fcg
         return top;
     }
 
-    FC_D uint32_t medium_push(uint32_t ms, uint32_t id, uint32_t& overflow)  // integrator.hpp:41-42
+    // integrator.hpp:41-42. The reference holds the vacuum + 9 media and does not check (a tenth push writes past its
+    // array); here a push beyond MEDIUM_STACK_CAP is dropped and counted: the counter is an error the hosts refuse
+    // (fcgpu_counters.medium_overflows). `deep` counts the pushes that land in the extension word (development statistic).
+    FC_D void medium_push(MStack& ms, uint32_t id, uint32_t& overflow, uint32_t& deep)
     {
-        uint32_t n = ms_count(ms);
+        const uint32_t n = ms_count(ms.w);
         if(n >= static_cast<uint32_t>(MEDIUM_STACK_CAP))
         {
             overflow += 1;
-            return ms;
+            return;
         }
-        ms = ms_set(ms, n, id);
-        return (ms & ~7u) | (n + 1);
+        if(n >= static_cast<uint32_t>(MEDIUM_STACK_INLINE)) deep += 1;
+        ms_set(ms, n, id);
+        ms.w = ms_with_count(ms.w, n + 1);
     }
 
     // Ray-origin offset of entity_scene::raycast / visibility (scene.hpp:85-93, 118-131, 146-152). The reference lifts the
@@ -193,7 +197,7 @@ namespace fcg
         PathState<R> st;
         st.beta[0] = a.x; st.beta[1] = a.y; st.beta[2] = a.z; st.pdf = a.w;
         st.p1[0] = b.x; st.p1[1] = b.y; st.p1[2] = b.z; st.flags = unpack_word(b.w);
-        st.w[0] = c.x; st.w[1] = c.y; st.w[2] = c.z; st.pad2 = R(0);
+        st.w[0] = c.x; st.w[1] = c.y; st.w[2] = c.z; st.ms_ext = c.w;
         return st;
     }
     // path state columns (Wavefront::st_c*), streamed like the other queue records
@@ -205,7 +209,7 @@ namespace fcg
     {
         st_stream(&Q.st_c0[set][i], Vec4<R>{st.beta[0], st.beta[1], st.beta[2], st.pdf});
         st_stream(&Q.st_c1[set][i], Vec4<R>{st.p1[0], st.p1[1], st.p1[2], pack_word(R(0), st.flags)});
-        st_stream(&Q.st_c2[set][i], Vec4<R>{st.w[0], st.w[1], st.w[2], R(0)});
+        st_stream(&Q.st_c2[set][i], Vec4<R>{st.w[0], st.w[1], st.w[2], st.ms_ext});
     }
 
     // ------------------------------------------------------------------ generate
@@ -332,7 +336,7 @@ namespace fcg
         uint32_t* stack = stack_lds + threadIdx.x;
         unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
         const uint32_t n = Q.counters->ray[B.parity][0];
-        uint32_t n_cast = 0, n_moverflow = 0, n_nodes = 0, n_prims = 0;
+        uint32_t n_cast = 0, n_moverflow = 0, n_mdeep = 0, n_nodes = 0, n_prims = 0;
         StackStats n_overflow;
         const bool last = B.h >= B.max_len;
         // dimensions per bounce: 6 for forward_mis (fcgpu_sampler.h), 3 for forward_bsdf
@@ -374,41 +378,46 @@ namespace fcg
                     bool alive = false;
                     uint32_t prim = INVALID_U32, entity = 0, key_hint = KEY_HINT_NONE;
                     vec3<R> p{}, nrm{};
+                    // the path's medium stack: its word came with the ray; the extension word (entries 5..8) stays in the
+                    // path-state column at the ray's index and is fetched only by paths that deep, written back only when changed
+                    MStack M{ms, 0u};
+                    if(ms_deep(ms)) M.ext = unpack_word(Q.st_c2[B.parity][slot].w);
+                    const uint32_t ext_in = M.ext;
                     if(T.pk != INVALID_U32)
                     {
                         hit_point(S, T.rc, T.pk, T.t_max, T.b0, T.b1, p, nrm, prim, entity, key_hint);
                         // a hinted triangle is no medium boundary and has one constant lobe: the record just loaded decides
                         const uint32_t med = key_hint != KEY_HINT_NONE ? 0u : static_cast<uint32_t>(S.entities[entity].medium);
-                        const uint32_t top = medium_top(S, ms);
+                        const uint32_t top = medium_top(S, M);
                         if(med == 0u)
                         {
-                            ms = ms_with_media(ms, top, top);
+                            M.w = ms_with_media(M.w, top, top);
                             alive = true;
                         }
                         else if(dot(dir, nrm) <= R(0))  // entering
                         {
                             if(S.media[med].priority <= S.media[top].priority)
                             {
-                                ms = medium_push(ms, med, n_moverflow);  // the re-cast leaves p INTO its medium, :36-44
+                                medium_push(M, med, n_moverflow, n_mdeep);  // the re-cast leaves p INTO its medium, :36-44
                                 p = lift_origin(S, p, nrm, dir, false);  // scene.hpp:86-93 with dot(n, w) <= 0
                                 recast = true;
                             }
                             else
                             {
-                                ms = ms_with_media(ms, top, med);
+                                M.w = ms_with_media(M.w, top, med);
                                 alive = true;
                             }
                         }
                         else
                         {
-                            uint32_t cnt = ms_count(ms), idx = 0;
+                            uint32_t cnt = ms_count(M.w), idx = 0;
                             for(; idx < cnt; ++idx)
-                                if(ms_get(ms, idx) == med) break;
+                                if(ms_get(M, idx) == med) break;
                             if(idx < cnt)  // else: leaving a medium never entered, the path dies (:88)
                             {
-                                ms = ms_set(ms, idx, ms_get(ms, cnt - 1));  // swap with last, :90-91
-                                ms = (ms & ~7u) | (cnt - 1);
-                                const uint32_t new_top = medium_top(S, ms);
+                                ms_set(M, idx, ms_get(M, cnt - 1));  // swap with last, :90-91
+                                M.w = ms_with_count(M.w, cnt - 1);
+                                const uint32_t new_top = medium_top(S, M);
                                 if(S.media[new_top].priority == S.media[top].priority)
                                 {
                                     p = lift_origin(S, p, nrm, dir, true);
@@ -416,12 +425,14 @@ namespace fcg
                                 }
                                 else
                                 {
-                                    ms = ms_with_media(ms, new_top, top);
+                                    M.w = ms_with_media(M.w, new_top, top);
                                     alive = true;
                                 }
                             }
                         }
                     }
+                    if(M.ext != ext_in) Q.st_c2[B.parity][slot].w = pack_word(R(0), M.ext);
+                    ms = M.w;
                     if(recast && ++guard < 32)
                     {
                         trav_begin(T, p, dir, consts<R>::inf);
@@ -505,7 +516,7 @@ namespace fcg
                         }
                         Q.hit_key[slot] = static_cast<uint8_t>(key);
                         if(Q.dec_hit)  // parity hook: what this path hit at vertex h
-                            Q.dec_hit[static_cast<size_t>(B.h - 1) * Q.dec_stride + path] = alive ? hit_word(T.pk, dec_lobe) : (key == Q_MISS ? DEC_MISS : DEC_DEAD);
+                            Q.dec_hit[static_cast<size_t>(B.h - 1) * Q.dec_stride + path] = alive ? hit_word(T.pk, dec_lobe) : (T.pk == INVALID_U32 ? DEC_MISS : DEC_DEAD);  // MISS: the ray left the scene (with or without an environment); DEAD: the path ended at a boundary (integrator.hpp:88)
                         slot = INVALID_U32;
                     }
                 }
@@ -571,6 +582,7 @@ namespace fcg
         if(SPILL) wave_stat_add(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost); else wave_stat_add_uniform(Q.stats, ST_STACK_OVERFLOW, n_overflow.lost);
         wave_stat_add(Q.stats, ST_STACK_SPILL, n_overflow.spilled);
         wave_stat_add(Q.stats, ST_MEDIUM_OVERFLOW, n_moverflow);
+        wave_stat_add(Q.stats, ST_MEDIUM_DEEP, n_mdeep);
         if(PROF) wave_stat_add(Q.stats, ST_NODES, n_nodes); else wave_stat_add_uniform(Q.stats, ST_NODES, n_nodes);
         wave_stat_add(Q.stats, ST_PRIMS, n_prims);
     }
@@ -862,6 +874,7 @@ namespace fcg
                 bool alive = false;
                 R pdf_w12 = R(0);
                 vec3<R> wn{};
+                uint32_t ms_ext_out = 0;
                 if constexpr(KEY != Q_FINAL)
                 {
                     // ---- scatter at p1 := sp.p (forward_mis_integrator.hpp:47-112 / :153-168)
@@ -971,14 +984,19 @@ namespace fcg
                         beta = beta * (value * (r_abs(dot(ng, wn)) / pdf_w12));  // :112
                         alive = true;
                         // helper::raycast entry: leaving p into its own medium pushes it, integrator.hpp:36-44
-                        uint32_t overflow = 0;
-                        if(ent.medium != 0 && dot(wn, ng) <= R(0)) ms = medium_push(ms, static_cast<uint32_t>(ent.medium), overflow);
+                        // (a path nested deeper than five media keeps entries 5..8 beside its state: MStack)
+                        MStack M{ms, 0u};
+                        if(ms_deep(ms)) M.ext = unpack_word(Q.st_c2[B.parity][hit_idx[i]].w);
+                        uint32_t overflow = 0, deep = 0;
+                        if(ent.medium != 0 && dot(wn, ng) <= R(0)) medium_push(M, static_cast<uint32_t>(ent.medium), overflow, deep);
                         if(overflow) atomicAdd(&Q.stats[ST_MEDIUM_OVERFLOW], 1ull);
+                        if(deep) atomicAdd(&Q.stats[ST_MEDIUM_DEEP], 1ull);
                         vec3<R> o = lift_origin(S, sp.p, ng, wn, dot(ng, wn) > R(0));
                         emit_ray = true;
                         r0 = Vec4<R>{o.x, o.y, o.z, wn.x};
                         r1 = Vec4<R>{wn.y, wn.z, R(0), R(0)};
-                        pack_ids(r1, path, ms & 0x007FFFFFu);
+                        pack_ids(r1, path, ms_strip_media(M.w));
+                        ms_ext_out = M.ext;
                         st.flags = DELTA ? 1u : 0u;
                     }
                 }
@@ -996,6 +1014,7 @@ namespace fcg
                     nst.p1[0] = sp.p.x; nst.p1[1] = sp.p.y; nst.p1[2] = sp.p.z;
                     nst.w[0] = wn.x; nst.w[1] = wn.y; nst.w[2] = wn.z;
                     nst.flags = st.flags;
+                    nst.ms_ext = pack_word(R(0), ms_ext_out);
                 }
             }
             uint32_t slot_r = 0, slot_s = 0;

@@ -62,7 +62,10 @@ namespace fcgpu
         // stack so that this cannot happen, and a host must not ship the frame if it did
         void verify()
         {
-            if(counters().stack_overflows != 0) throw std::runtime_error("fcgpu: traversal stack overflowed (stack_overflows != 0): the image is not valid");
+            const fcgpu_counters c = counters();
+            if(c.stack_overflows != 0) throw std::runtime_error("fcgpu: traversal stack overflowed (stack_overflows != 0): the image is not valid");
+            // more than the reference's 9 nested media on one path (integrator.hpp:24): the push was dropped
+            if(c.medium_overflows != 0) throw std::runtime_error("fcgpu: a path nested more than 9 media (medium_overflows != 0): the image is not valid");
         }
 
         // this renderer's share of a frame rendered by several GPUs: the bands of `band_rows` film rows b with

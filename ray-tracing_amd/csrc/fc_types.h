@@ -171,7 +171,8 @@ namespace fcg
     };
 
     constexpr int MAX_MEDIA = 15;       // 4-bit medium ids, 0 = vacuum
-    constexpr int MEDIUM_STACK_CAP = 5; // nested media beyond the vacuum (reference: 9, integrator.hpp:24)
+    constexpr int MEDIUM_STACK_CAP = 9; // nested media beyond the vacuum: the reference's capacity (integrator.hpp:24: buffer_capacity = 10)
+    constexpr int MEDIUM_STACK_INLINE = 5;  // of those, the entries that travel in the ray / hit records' own word (MStack)
 
     template<typename R>
     struct MediumRec
@@ -322,16 +323,36 @@ namespace fcg
     FC_HD uint32_t unpack_word(float v) { return __builtin_bit_cast(uint32_t, v); }
     FC_HD uint32_t unpack_word(double v) { return static_cast<uint32_t>(__builtin_bit_cast(uint64_t, v)); }
 
-    // medium stack word: count(3) | 5 x id(4) | above(4) | below(4)
-    FC_HD uint32_t ms_count(uint32_t m) { return m & 7u; }
-    FC_HD uint32_t ms_get(uint32_t m, uint32_t i) { return (m >> (3 + 4 * i)) & 15u; }
-    FC_HD uint32_t ms_set(uint32_t m, uint32_t i, uint32_t id) { return (m & ~(15u << (3 + 4 * i))) | (id << (3 + 4 * i)); }
-    FC_HD uint32_t ms_above(uint32_t m) { return (m >> 23) & 15u; }
-    FC_HD uint32_t ms_below(uint32_t m) { return (m >> 27) & 15u; }
-    FC_HD uint32_t ms_with_media(uint32_t m, uint32_t above, uint32_t below)
+    // Priority-medium stack of a path (helper::buffer_, integrator.hpp:24-31: the vacuum + at most 9 media).
+    //   w   = count bits 0..2 | 5 x id(4) | above(4) | below(4) | count bit 3: the word of the ray and hit records
+    //   ext = ids 5..8 (4 x 4 bits): only paths nested deeper than five media ever touch it. It travels in the fourth
+    //         word of the path-state column st_c2 (same index as the ray / hit record), which k_extend and k_shade read
+    //         only when the count in `w` says so; everybody else moves one word as before.
+    struct MStack
     {
-        return (m & 0x007FFFFFu) | (above << 23) | (below << 27);
+        uint32_t w, ext;
+    };
+    FC_HD uint32_t ms_count(uint32_t w) { return (w & 7u) | ((w >> 31) << 3); }
+    FC_HD bool ms_deep(uint32_t w) { return ms_count(w) > static_cast<uint32_t>(MEDIUM_STACK_INLINE); }
+    FC_HD uint32_t ms_with_count(uint32_t w, uint32_t n) { return (w & 0x7FFFFFF8u) | (n & 7u) | ((n >> 3) << 31); }
+    FC_HD uint32_t ms_get(const MStack& m, uint32_t i)
+    {
+        return i < static_cast<uint32_t>(MEDIUM_STACK_INLINE) ? (m.w >> (3 + 4 * i)) & 15u : (m.ext >> (4 * (i - MEDIUM_STACK_INLINE))) & 15u;
     }
+    FC_HD void ms_set(MStack& m, uint32_t i, uint32_t id)
+    {
+        if(i < static_cast<uint32_t>(MEDIUM_STACK_INLINE))
+            m.w = (m.w & ~(15u << (3 + 4 * i))) | (id << (3 + 4 * i));
+        else
+            m.ext = (m.ext & ~(15u << (4 * (i - MEDIUM_STACK_INLINE)))) | (id << (4 * (i - MEDIUM_STACK_INLINE)));
+    }
+    FC_HD uint32_t ms_above(uint32_t w) { return (w >> 23) & 15u; }
+    FC_HD uint32_t ms_below(uint32_t w) { return (w >> 27) & 15u; }
+    FC_HD uint32_t ms_with_media(uint32_t w, uint32_t above, uint32_t below)
+    {
+        return (w & 0x807FFFFFu) | (above << 23) | (below << 27);
+    }
+    FC_HD uint32_t ms_strip_media(uint32_t w) { return w & 0x807FFFFFu; }  // what travels with a ray: the stack without above / below
 
     // per-path persistent state (the record the Wavefront's st_c0..2 columns hold, 16 bytes of it each): 48 B in fp32, 96 B in fp64. The radiance a path has gathered is NOT part of it: it
     // lives in the Wavefront's `li_shadow` column, which only the hits that add to it touch (emitter and environment
@@ -344,7 +365,7 @@ namespace fcg
         R p1[3];      // previous vertex (un-offset), for transmittance and the area-measure pdf
         uint32_t flags;  // bit0: last lobe was delta (or camera segment): emitter hits un-weighted (in fp64 the compiler pads to 8)
         R w[3];       // direction of the segment that produced the current hit (w12)
-        R pad2;
+        R ms_ext;     // MStack::ext as a packed word (0 unless the path is nested deeper than five media)
     };
 
     static_assert(sizeof(PathState<float>) == 48 && sizeof(PathState<double>) == 96, "one path state = three 16-byte (32-byte) pieces");
@@ -368,7 +389,7 @@ namespace fcg
 
     enum StatIndex
     {
-        ST_CLOSEST = 0, ST_SHADOW = 1, ST_OCCLUDED = 2, ST_NAN = 3, ST_STACK_OVERFLOW = 4, ST_MEDIUM_OVERFLOW = 5, ST_NODES = 6, ST_PRIMS = 7, ST_STACK_SPILL = 8, ST_COUNT = 9
+        ST_CLOSEST = 0, ST_SHADOW = 1, ST_OCCLUDED = 2, ST_NAN = 3, ST_STACK_OVERFLOW = 4, ST_MEDIUM_OVERFLOW = 5, ST_NODES = 6, ST_PRIMS = 7, ST_STACK_SPILL = 8, ST_MEDIUM_DEEP = 9, ST_COUNT = 10
     };
 
     template<typename R>

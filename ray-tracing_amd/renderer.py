@@ -286,6 +286,15 @@ class GpuRenderer:
         for tile in (self.tiles if self.tiles is not None else [None]):
             self.ctx.render_pass(sample_begin, n, self.integrator, self.max_path_length, self.visible, tile)
         self.ctx.sync()
+        self.verify()
+
+    def verify(self):
+        """gpu_renderer::verify (csrc/fc_renderer.hpp): a dropped traversal-stack or medium-stack push means a wrong image."""
+        c = self.ctx.counters()
+        if c.stack_overflows != 0:
+            raise FcgpuError(A.E_LIMIT, "traversal stack overflowed (stack_overflows != 0): the image is not valid")
+        if c.medium_overflows != 0:
+            raise FcgpuError(A.E_LIMIT, "a path nested more than 9 media (medium_overflows != 0): the image is not valid")
 
     def film(self):
         return self.ctx.read_film()

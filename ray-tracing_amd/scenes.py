@@ -400,6 +400,27 @@ def nested_media(width=256, height=256, smooth=True, env=(1.0, 1.0, 1.0)):
     return sc
 
 
+def nested_deep(width=64, height=64, depth=9, smooth=True):
+    """`depth` concentric glass spheres, each bounding its own medium, priorities alternating so that every second
+    boundary is hidden by the medium around it (integrator.hpp:66-71: pushed by the re-cast) and the others refract
+    (pushed when the path leaves the boundary inwards, :36-44): a path that reaches the core holds `depth` media on the
+    helper's stack, the reference's capacity at depth 9 (integrator.hpp:24: vacuum + 9). depth 10 is beyond what the
+    reference can hold (it writes past its array): only the device's refusal is tested there."""
+    sc = Scene()
+    r = (0.0, 0.0) if smooth else (0.15, 0.15)
+    white = (1, 1, 1)
+    sc.entity(sc.plane((0, 0, 0), (30, 30)), sc.diffuse((0.5, 0.5, 0.5)))
+    prio = [3, 1, 4, 2, 5, 3, 6, 4, 7, 5, 8, 6]
+    for k in range(depth):
+        tint = (0.9 - 0.05 * (k % 3), 0.95 - 0.04 * ((k + 1) % 3), 0.92 - 0.05 * ((k + 2) % 3))
+        sc.entity(sc.sphere((0.02 * k, 2.0, 0.01 * k), 2.0 - 0.18 * k), sc.glass(white, white, r),
+                  medium=sc.medium(prio[k], 1.05 + 0.04 * k, tint, 0.3))
+    sc.entity(sc.sphere((3.0, 5.0, -2.0), 0.7), sc.diffuse((0.1, 0.1, 0.1)), emission=(1, 0.9, 0.8), strength=30.0)
+    sc.set_camera((0.5, 3.5, -9.0), (math.radians(10.0), 0.0, 0.0), math.radians(40.0), width, height)
+    sc.set_env((0.8, 0.9, 1.0))
+    return sc
+
+
 def primitives_zoo(width=128, height=128):
     """All three surface kinds with rotations, a mesh with normals + uvs, every material class,
     a mesh emitter and a plane emitter -- small, for exhaustive parity tests."""
@@ -579,7 +600,7 @@ def normal_mapped_scene(width=96, height=64):
     return sc
 
 
-def mask_scene(width=600, height=900, detail=48, texture_size=64):
+def mask_scene(width=600, height=900, detail=48, texture_size=64, min_roughness=0.02, variant=""):
     """Stand-in for scene_mask (example_scenes.hpp:316-361, BASELINE config 4): one mesh with normals and uvs under
     standard_material{basecolor srgb8, metalness r8, roughness r8, ior 1.45, normal rgb8} (all bilinear), lit only by
     a texture_infinity_area_light (rgb32, bilinear, 4x4 integral samples, distribution = image resolution), thin-lens
@@ -620,17 +641,31 @@ def mask_scene(width=600, height=900, detail=48, texture_size=64):
     base = np.stack([0.55 + 0.4 * stripes, 0.25 + 0.5 * (1 - stripes) * yy, 0.15 + 0.25 * xx], -1)
     gold = (np.abs(yy - 0.5) < 0.08) | (np.hypot(xx - 0.5, yy - 0.8) < 0.12)  # gilded band and chin
     base[gold] = (0.95, 0.75, 0.35)
-    basecolor = sc.texture(sc.image(np.round(255 * np.clip(base, 0, 1)).astype(np.uint8), "srgb8"), "bilinear")
-    metalness = sc.texture(sc.image(np.where(gold, 255, 0).astype(np.uint8), "r8"), "bilinear")
-    rough = np.clip(0.25 + 0.35 * stripes + 0.1 * rng.standard_normal((n, n)), 0.02, 1.0)
-    rough[gold] = 0.12
-    roughness = sc.texture(sc.image(np.round(255 * rough).astype(np.uint8), "r8"), "bilinear")
-    normal = sc.texture(sc.image(normal_map_image(n, n, "rgb8", 0.45, 5), "rgb8"), "bilinear")
-    sc.entity(mesh, sc.material(A.MATERIAL_STANDARD, ior=1.45, tex_color_a=basecolor, tex_metalness=metalness, tex_roughness=roughness, tex_normal=normal))
+    filt = "box" if "boxtex" in variant else "bilinear"
+    basecolor = sc.texture(sc.image(np.round(255 * np.clip(base, 0, 1)).astype(np.uint8), "srgb8"), filt)
+    metalness = sc.texture(sc.image(np.where(gold, 255, 0).astype(np.uint8), "r8"), filt)
+    rough = np.clip(0.25 + 0.35 * stripes + 0.1 * rng.standard_normal((n, n)), min_roughness, 1.0)
+    rough[gold] = max(0.12, min_roughness)
+    roughness = sc.texture(sc.image(np.round(255 * rough).astype(np.uint8), "r8"), filt)
+    normal = sc.texture(sc.image(normal_map_image(n, n, "rgb8", 0.45, 5), "rgb8"), filt)
+    # `variant` (development probes only: tools/c4_variants.py): drops one feature at a time
+    tex = dict(tex_color_a=basecolor, tex_metalness=metalness, tex_roughness=roughness, tex_normal=normal)
+    if "nonormal" in variant:
+        del tex["tex_normal"]
+    if "notex" in variant:
+        tex = {}
+    for k in ("color_a", "metalness", "roughness"):
+        if "only_" + k in variant:
+            tex = {"tex_" + k: tex["tex_" + k]}
+    sc.entity(mesh, sc.material(A.MATERIAL_STANDARD, color_a=(0.6, 0.4, 0.3), roughness=(0.3, 0.3), metalness=0.3, ior=1.45, **tex))
 
     env = sc.image(sky_image(64, 32, "rgb32"), "rgb32")
-    sc.set_env_texture(env, strength=1.0, rotation=(0.0, 0.0, 0.0), filter="bilinear", integral_sample_count=4)
-    sc.set_camera((2.367, 3.216, 6.485), (0.0, math.radians(196.42), 0.0), math.radians(45.0), width, height, lens_radius=0.05, focus_distance=6.0)
+    if "constenv" in variant:
+        sc.set_env((1.0, 0.9, 0.8))
+    else:
+        sc.set_env_texture(env, strength=1.0, rotation=(0.0, 0.0, 0.0), filter="box" if "boxenv" in variant else "bilinear", integral_sample_count=4)
+    sc.set_camera((2.367, 3.216, 6.485), (0.0, math.radians(196.42), 0.0), math.radians(45.0), width, height,
+                  lens_radius=0.0 if "pinhole" in variant else 0.05, focus_distance=6.0)
     return sc
 
 
@@ -842,6 +877,6 @@ def random_scene(seed=0, width=32, height=24):
     return sc
 
 
-BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "primitives_zoo": primitives_zoo,
+BUILDERS = {"room": room, "room_planes": room_planes, "nested_media": nested_media, "nested_deep": nested_deep, "primitives_zoo": primitives_zoo,
             "env_texture_scene": env_texture_scene, "textured_scene": textured_scene, "normal_mapped_scene": normal_mapped_scene, "mask_scene": mask_scene, "random_scene": random_scene,
             "material_ball_scene": material_ball_scene, "glass_scene": glass_scene, "normals_scene": normals_scene}

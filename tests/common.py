@@ -89,3 +89,103 @@ def cards_rays(n_rays, seed):
     rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
     rays["t_max"] = np.inf
     return rays
+
+
+CROP_FIXTURES = sorted(f[5:-4] for f in os.listdir(GOLDEN) if f.startswith("crop_"))
+
+
+def load_crop(name):
+    """A crop of a BASELINE configuration at the size it runs (oracle/make_golden.py: CROPS) -> (fixture, scene, tile)."""
+    z = np.load(os.path.join(GOLDEN, f"crop_{name}.npz"))
+    scene = S.BUILDERS[str(z["builder"])](**ast.literal_eval(str(z["kwargs"])))
+    return z, scene, tuple(int(v) for v in z["tile"])
+
+
+def render_crop(scene, z, tile, precision, decision_log=False, **options):
+    """The crop through the C-ABI -> (rgb_sum of the crop, sample count, counters[, hit words, flag words])."""
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision=precision, **options)
+        ctx.upload_scene(scene)
+        ctx.set_sampler(int(z["seed"]))
+        if decision_log:
+            ctx.set_decision_log(True)
+        ctx.render_pass(0, int(z["spp"]), A.INTEGRATOR_MIS, int(z["max_path_length"]), True, tile)
+        rgb, n = ctx.read_film()
+        c = ctx.counters()
+        log = ctx.read_decision_log() if decision_log else ()
+    x0, y0, w, h = tile
+    return (rgb[y0:y0 + h, x0:x0 + w], n, c) + tuple(log)
+
+
+DEC_MISS, DEC_DEAD = 0xFFFFFFFE, 0xFFFFFFFD
+DEC_SAMPLED, DEC_TRANSMITTED, DEC_SHADOW_CAST, DEC_OCCLUDED = 2, 4, 8, 16
+
+
+def divergence_table(h64, f64, img64, h32, f32, img32, npix, out=print):
+    """Where do the fp32 and the fp64 render of the SAME samples part ways? Compares the decision logs
+    (fcgpu_set_decision_log: per vertex and path the hit word and the DEC_* flags) vertex by vertex: the first vertex where
+    they differ is the path's divergence, classified by what differs there; then attributes the pixels that differ by more
+    than 1e-2 to those paths. Returns the numbers the tests gate; `out` prints the table (tools/divergence.py)."""
+    bounces, paths = h64.shape
+    path_bits = ~np.uint32(DEC_OCCLUDED | DEC_SHADOW_CAST)  # the path itself, not its shadow ray's fate
+    hit_diff = h64 != h32
+    diff = hit_diff | ((f64 & path_bits) != (f32 & path_bits))
+    first = np.where(diff.any(axis=0), diff.argmax(axis=0), -1)
+    diverged = first >= 0
+    out(f"{paths} paths, {bounces} vertices each; paths whose decisions differ between fp32 and fp64: {diverged.sum()} = {diverged.mean():.2e}")
+    idx = np.flatnonzero(diverged)
+    fb = first[idx]
+    a, b = h64[fb, idx], h32[fb, idx]
+    x = f64[fb, idx] ^ f32[fb, idx]
+    both_hit = (a < DEC_DEAD) & (b < DEC_DEAD)
+    hd = a != b
+    other_prim = hd & both_hit & ((a & 0x3FFFFFFF) != (b & 0x3FFFFFFF))
+    same_key = ((x >> 8) & 15) == 0
+    classes = {
+        "closest hit: another primitive": other_prim,
+        "lobe pick (same primitive)": hd & both_hit & ~other_prim,
+        "hit on one side, miss / end on the other": hd & ~both_hit,
+        "lobe type (same hit)": ~hd & ~same_key,
+        "BSDF sample succeeds on one side only": ~hd & same_key & ((x & DEC_SAMPLED) != 0),
+        "reflect / transmit pick (Fresnel)": ~hd & same_key & ((x & DEC_SAMPLED) == 0) & ((x & DEC_TRANSMITTED) != 0),
+    }
+    out("first divergence by cause:")
+    for name, m in sorted(classes.items(), key=lambda kv: -kv[1].sum()):
+        per_vertex = np.bincount(fb[m] + 1, minlength=bounces + 1)[1:]
+        out(f"  {name:44s} {m.sum():7d} = {m.sum() / paths:.2e} of the paths; by vertex 1..{bounces}: {per_vertex.tolist()}")
+    ka, kb = (a[other_prim] >> 28) & 3, (b[other_prim] >> 28) & 3
+    tri = (ka == 0) & (kb == 0)
+    if other_prim.any():
+        names = {0: "triangle", 1: "sphere", 2: "plane"}
+        pairs = {}
+        for p, q in zip(ka, kb):
+            pairs[(names[int(p)], names[int(q)])] = pairs.get((names[int(p)], names[int(q)]), 0) + 1
+        out(f"  'another primitive' by kinds (fp64, fp32): {pairs}")
+        d = np.abs((a[other_prim][tri] & 0x0FFFFFFF).astype(np.int64) - (b[other_prim][tri] & 0x0FFFFFFF).astype(np.int64))
+        out(f"  triangle / triangle cases whose records are neighbours in leaf order (|index difference| <= 2): {(d <= 2).mean() if len(d) else 0:.2f}")
+    # shadow rays: cast / occluded differences at vertices the two paths still share
+    sh = ((f64 ^ f32) & (DEC_SHADOW_CAST | DEC_OCCLUDED)) != 0
+    before = (first[None, :] < 0) | (np.arange(bounces)[:, None] <= first[None, :])
+    sh_only = sh & before & ~diff
+    n_shadow = max(1, int(((f64 & DEC_SHADOW_CAST) != 0).sum()))
+    out(f"visibility differences at vertices the two paths still share: {sh_only.sum()} = {sh_only.sum() / n_shadow:.2e} of the shadow rays")
+    floor = 1e-3 * float(np.abs(img64).mean())
+    rel = (np.abs(img32 - img64).max(axis=2) / np.maximum(np.abs(img64).max(axis=2), floor)).ravel()
+    pix_of_path = np.arange(paths) % npix
+    has_div = np.zeros(npix, bool)
+    has_div[pix_of_path[diverged]] = True
+    has_sh = np.zeros(npix, bool)
+    has_sh[pix_of_path[sh_only.any(axis=0)]] = True
+    bad = rel > 1e-2
+    clean = ~has_div & ~has_sh
+    out(f"pixels beyond 1e-2 (fp32 against fp64): {bad.sum()} = {bad.mean():.4f}; of these {(bad & has_div).sum()} hold a diverged path, "
+        f"{(bad & ~has_div & has_sh).sum()} only a visibility difference, {(bad & clean).sum()} neither")
+    out(f"pixels with a diverged path: {has_div.mean():.4f}; pixels without any difference: median rel err {np.median(rel[clean]):.2e}, maximum {rel[clean].max():.2e}")
+    return {
+        "paths": int(paths), "diverged_fraction": float(diverged.mean()),
+        "first_is_another_primitive": float(other_prim.sum() / max(1, diverged.sum())),
+        "first_is_triangle_triangle": float(tri.sum() / max(1, diverged.sum())),
+        "visibility_only_fraction": float(sh_only.sum() / n_shadow),
+        "bad_pixels": int(bad.sum()), "bad_pixels_unexplained": int((bad & clean).sum()),
+        "clean_median_rel_err": float(np.median(rel[clean])), "clean_max_rel_err": float(rel[clean].max()),
+    }

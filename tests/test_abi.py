@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(A.EXPORTS)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.fcgpu_version() == 1003
+    assert lib.fcgpu_version() == 1004
 
 
 def test_struct_layouts_match_header():
@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(A.Entity) == 16 + 4 * 8
     assert C.sizeof(A.Camera) == 9 * 8 + 8
     assert C.sizeof(A.Ray) == 56 and C.sizeof(A.Hit) == 32
-    assert C.sizeof(A.Counters) == 16 * 8
+    assert C.sizeof(A.Counters) == 18 * 8
     assert C.sizeof(A.Options) == 32
 
 

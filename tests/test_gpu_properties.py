@@ -551,3 +551,66 @@ def test_batch_size_is_halved_when_the_device_cannot_hold_the_queues():
     assert m == n and c.stack_overflows == 0
     assert c.kernel_launches >= 2 * 69  # at least two batches' worth of launches (69 each): the pass was split
     assert np.array_equal(rgb, want)
+
+
+def test_8k_frame_dealt_in_bands_to_eight_ranks_is_bit_exact():
+    """BASELINE config 5's one-GPU half (7680 x 4320, tile-sharded over 8 GPUs): the 8 ranks' shares of the 8K frame, rendered
+    through fcgpu_render_bands as 8 calls (bands of 4 rows dealt round-robin, one pass per rank), together cover every pixel
+    once, and bands owned by three different ranks equal a plain fcgpu_render_pass of the same rows bit for bit."""
+    W, H, rows, world = 7680, 4320, 4, 8
+    sc = S.room(width=W, height=H, tess=64)
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision="f32")
+        ctx.upload_scene(sc)
+        ctx.set_sampler(0)
+        for rank in range(world):
+            ctx.render_bands(rows, rank, world, 0, 1)
+        gathered, n = ctx.read_film()
+        c = ctx.counters()
+        assert n == W * H and c.stack_overflows == 0 and c.nan_samples == 0
+        nbands = H // rows
+        picks = [1, 8 * (nbands // 16) + 3, nbands - 2]  # owners 1, 3 and 6
+        assert sorted({b % world for b in picks}) == [1, 3, 6]
+        kept = {b: gathered[b * rows:(b + 1) * rows].copy() for b in picks}
+        lit = float((gathered.max(axis=2) > 0).mean())
+        del gathered
+        ctx.clear_film()
+        for b in picks:
+            ctx.render_pass(0, 1, tile=(0, b * rows, W, rows))
+        plain, m = ctx.read_film()
+    assert m == len(picks) * rows * W
+    assert lit > 0.9  # a closed room: nearly every pixel of every rank's share received light
+    for b in picks:
+        assert np.array_equal(plain[b * rows:(b + 1) * rows], kept[b]), b
+
+
+def test_paths_nested_nine_media_deep_use_the_extension_word():
+    """The priority-medium stack holds the reference's 9 media (integrator.hpp:24): entries 6..9 live in the extension word
+    beside the path state. nested_deep(9) must really reach them (medium_deep_pushes > 0), lose nothing, and -- the
+    parity itself is test_gpu_parity's film_nested_deep9* against the real reference -- render the same film in small batches."""
+    sc = S.nested_deep(40, 40, depth=9)
+    out = []
+    for cap in (0, 512):
+        with R.GpuContext(0) as ctx:
+            ctx.set_options(precision="f64", max_paths_in_flight=cap)
+            ctx.upload_scene(sc)
+            ctx.set_sampler(7)
+            ctx.render_pass(0, 4, A.INTEGRATOR_MIS, 24, True)
+            rgb, n = ctx.read_film()
+            c = ctx.counters()
+        assert c.medium_overflows == 0 and c.reserved[0] == 0
+        assert c.medium_deep_pushes > 0, "no path nested deeper than five media: the scene does not cover the extension word"
+        out.append((rgb, int(c.medium_deep_pushes), int(c.closest_rays)))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:]
+
+
+def test_a_tenth_nested_medium_is_refused_not_rendered():
+    """Ten nested media are beyond the reference's own capacity (it writes past helper::buffer_). The device drops the push and
+    counts it; the counter is an error: GpuRenderer.run() (like gpu_renderer::verify() in C++ and bench.py) refuses the frame."""
+    sc = S.nested_deep(40, 40, depth=10)
+    r = R.GpuRenderer(sc, integrator="mis", max_path_length=24, sample_count=4, seed=7, precision="f32")
+    with pytest.raises(R.FcgpuError) as e:
+        r.run()
+    assert e.value.code == A.E_LIMIT and "medium_overflows" in str(e.value)
+    assert r.ctx.counters().medium_overflows > 0
+    r.close()
