@@ -41,21 +41,39 @@ VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 (vector)
 # tools/pmc_summary.py; the passes themselves are kept under profiles/ (named in the file's "source")
 PMC_SUMMARY = os.path.join(ROOT, "ray-tracing_amd", "pmc_summary.json")
 
-# fp32 parity gate (same sample streams, against the CPU baseline's film): thresholds as a function of the samples per
-# pixel, because a pixel is the sum of its paths and ONE path whose discrete decision flips on a rounding (a hit at a
-# triangle edge, a Fresnel pick) moves it: measured 1.14 % of the pixels beyond 1e-2 at 16 spp (7e-4 per path).
-PARITY_MEDIAN_REL_ERR = 5e-6
-PARITY_BEYOND_1E2_PER_SPP = 1.1e-3   # fraction within 1e-2 >= 1 - 1.1e-3 * spp
-PARITY_MEAN_RATIO = 1e-3
+# fp32 parity gate (same sample streams, against the CPU baseline's film). ONE bar, stated here, asserted with the same
+# numbers by tests/test_gpu_headline.py on the committed reference crop and quoted in DESIGN.md section 4: at 16 spp at
+# least 98.5 % of the pixels within 1e-2 and 97 % within 1e-3 of the reference (measured 98.9 % / 97.6 %), median relative
+# error <= 2e-6 (measured 5e-7), image mean within 5e-4. A pixel is the sum of its paths and ONE path whose discrete
+# decision flips on a rounding (a hit across a triangle edge: 5.3e-3 of the paths) moves it, so the allowed fractions
+# beyond the bounds grow in proportion to the samples per pixel; they are capped, so that the gate can always fail.
+PARITY_MEDIAN_REL_ERR = 2e-6
+PARITY_WITHIN_1E2_MIN_16SPP = 0.985
+PARITY_WITHIN_1E3_MIN_16SPP = 0.97
+PARITY_MEAN_RATIO = 5e-4
 PARITY_REL_MSE = 1e-3
 
 
-def launch_ranks(args):
-    """--gpus N without an external launcher: N fresh ranks via torch.distributed.run. Nothing here touches a GPU
-    (counting devices does not initialise HIP), so no process that holds a GPU context is ever replaced."""
-    import torch
+def parity_fraction_floors(spp):
+    """(within 1e-2 >=, within 1e-3 >=) at `spp` samples per pixel: the 16-spp bars scaled by the path count, never below 0.5."""
+    k = spp / 16.0
+    return max(0.5, 1.0 - (1.0 - PARITY_WITHIN_1E2_MIN_16SPP) * k), max(0.5, 1.0 - (1.0 - PARITY_WITHIN_1E3_MIN_16SPP) * k)
 
-    have = torch.cuda.device_count()
+
+def visible_gpus():
+    """GPUs a rank could use, counted in a throw-away child process: the launcher itself never loads a GPU runtime, so
+    whatever counting devices initialises dies with that child."""
+    probe = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE, text=True)
+    try:
+        return int(probe.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def launch_ranks(args):
+    """--gpus N without an external launcher: N fresh ranks via torch.distributed.run. Nothing in this process touches a
+    GPU (devices are counted by a child), so no process that holds a GPU context is ever replaced."""
+    have = visible_gpus()
     if have < args.gpus and not (args.backend == "gloo" and have >= 1):
         print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible: refusing to run fewer ranks than asked", file=sys.stderr)
         return 2
@@ -82,14 +100,36 @@ def launch_ranks(args):
 
 
 def cpu_model():
+    """'model name (family F model M)' of the first CPU in /proc/cpuinfo: virtualised hosts shorten the name ("AMD EPYC"),
+    the family / model numbers still say which part it is."""
+    want = {"model name": None, "cpu family": None, "model": None}
     try:
         with open("/proc/cpuinfo") as f:
             for ln in f:
-                if ln.startswith("model name"):
-                    return ln.split(":", 1)[1].strip()
+                k = ln.split(":", 1)[0].strip()
+                if k in want and want[k] is None:
+                    want[k] = ln.split(":", 1)[1].strip()
+                if all(v is not None for v in want.values()):
+                    break
     except OSError:
         pass
-    return "unknown"
+    if want["model name"] is None:
+        return "unknown"
+    return f'{want["model name"]} (family {want["cpu family"]} model {want["model"]})'
+
+
+def cpu_threads():
+    """Worker threads of the CPU baseline = this job's share of the host, as SURVEY 8(d) asks (the reference's
+    worker_count = hardware_concurrency()): the CPUs the process may run on, capped by OMP_NUM_THREADS where the
+    operator set it (on the GPU box it is the one-GPU share of the machine, 16, while os.cpu_count() shows all of the
+    host's logical CPUs; more threads than the share only time-slice). All three numbers go into the line."""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = logical
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or affinity
+    return max(1, min(share, affinity)), logical, affinity
 
 
 def cpu_baseline(S, A, args):
@@ -102,7 +142,7 @@ def cpu_baseline(S, A, args):
     scene = S.room(args.width, args.height, tess=args.tess)
     kind = "reference" if pyref.have_reference() else "port"
     backend = pyref.reference() if kind == "reference" else pyref.restatement("f64")
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    cores, logical, affinity = cpu_threads()
     sc = backend.scene(scene)
     tw, th = args.width // 4, args.height // 4
     tile = ((args.width - tw) // 2, (args.height - th) // 2, tw, th)
@@ -119,6 +159,8 @@ def cpu_baseline(S, A, args):
     out = {
         "value": rays / seconds / 1e6, "unit": "Mrays/s", "samples_per_s": samples / seconds, "cores": cores, "kind": kind,
         "seconds": seconds, "rays_per_sample": rays / samples, "cpu_model": cpu_model(),
+        "host_logical_cpus": logical, "affinity_cpus": affinity, "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),
+        "cores_rule": "min(OMP_NUM_THREADS = the job's share of the host, CPUs in the affinity mask)",
         "sample": f"centre crop {tw}x{th} of the {args.width}x{args.height} frame, {args.cpu_spp} spp, Forward MIS, max_path_length 10, "
                   "same scene and sample streams",
     }
@@ -154,13 +196,15 @@ def parity_gate(ctx, A, args, ref_rgb, tile, ref_nan, kind):
         "nan_samples": [int(c.nan_samples), ref_nan], "stack_overflows": int(c.stack_overflows), "medium_overflows": int(c.medium_overflows),
     }
     f64 = args.precision == "f64"
+    floor2, floor3 = parity_fraction_floors(args.parity_spp)
     th = {
         "median_rel_err_max": 1e-12 if f64 else PARITY_MEDIAN_REL_ERR,
-        "fraction_within_1e-2_min": 1.0 if f64 else 1.0 - PARITY_BEYOND_1E2_PER_SPP * args.parity_spp,
+        "fraction_within_1e-2_min": 1.0 if f64 else floor2, "fraction_within_1e-3_min": 1.0 if f64 else floor3,
         "mean_ratio_tol": 1e-9 if f64 else PARITY_MEAN_RATIO, "rel_mse_max": 1e-18 if f64 else PARITY_REL_MSE,
     }
     out["thresholds"] = th
     out["pass"] = bool(out["median_rel_err"] <= th["median_rel_err_max"] and out["fraction_within_1e-2"] >= th["fraction_within_1e-2_min"]
+                       and out["fraction_within_1e-3"] >= th["fraction_within_1e-3_min"]
                        and abs(out["mean_ratio"] - 1.0) <= th["mean_ratio_tol"] and mse <= th["rel_mse_max"]
                        and out["nan_samples"][0] == out["nan_samples"][1] and out["stack_overflows"] == 0 and out["medium_overflows"] == 0)
     return out
@@ -280,11 +324,21 @@ def main():
     # tiles:   every rank renders the same sample indices [0, total) of the pixels it owns
     base = 0 if tiles else rank * total_steps * spp
 
-    def render_step(k):
-        if tiles:
-            ctx.render_bands(args.band_rows, rank, world, base + k * spp, spp)
-        else:
-            ctx.render_pass(base + k * spp, spp)
+    def render_steps(first, count):
+        """steps [first, first + count). samples: one pass of `spp` samples of the full frame per step. tiles: a rank owns
+        1 / world of the pixels, so it takes the samples of `world` steps in ONE pass: its batches stay at the 2^27 paths
+        they have on one GPU (a pass of spp samples over 1 / 8 of the frame would run 16.6 M-path batches at N = 8, which
+        the batch-size table of DESIGN.md section 5 prices at -14 %); the film does not depend on how the sample range
+        is cut into passes (one writer per pixel, samples added in index order)."""
+        if not tiles:
+            for k in range(first, first + count):
+                ctx.render_pass(base + k * spp, spp)
+            return
+        k = first
+        while k < first + count:
+            n = min(world, first + count - k)
+            ctx.render_bands(args.band_rows, rank, world, base + k * spp, n * spp)
+            k += n
 
     def barrier():
         ctx.sync()
@@ -295,8 +349,7 @@ def main():
             if nccl:
                 torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        render_step(w)
+    render_steps(0, args.warmup)
     ctx.sync()
     if dist is not None and args.warmup > 0:
         # warm the collective too: RCCL sets its reduce channels up on first use, which belongs to warm-up
@@ -311,11 +364,15 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        render_step(args.warmup + k)
+    render_steps(args.warmup, args.steps)
+    reduce_s = 0.0
     if dist is not None:
         ctx.sync()
+        t1 = time.perf_counter()
         reduce_films()
+        if nccl:
+            torch.cuda.synchronize()
+        reduce_s = time.perf_counter() - t1
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -326,11 +383,11 @@ def main():
     rays = c.closest_rays + c.shadow_rays
     samples = local_samples
     if dist is not None:
-        t = torch.tensor([elapsed, float(samples), float(rays)], dtype=torch.float64, device=torch.device("cuda", local) if nccl else "cpu")
+        t = torch.tensor([elapsed, float(samples), float(rays), reduce_s], dtype=torch.float64, device=torch.device("cuda", local) if nccl else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, samples, rays = float(tmax[0]), float(t[1]), float(t[2])
+        elapsed, samples, rays, reduce_s = float(tmax[0]), float(t[1]), float(t[2]), float(tmax[3])
 
     tile_check = None
     if tiles and rank == 0:
@@ -371,7 +428,12 @@ def main():
                     f"sample-pass sharding over {world} ranks + film reduce") + (" (RCCL over xGMI, one GPU per rank)" if nccl else
                                                                                   " (gloo rehearsal: ranks share GPUs, films reduced through the host)"),
                 "rccl_ranks": dist.get_world_size() if nccl else 0, "backend": args.backend if dist is not None else None,
+                # paths of one rank's largest pass (the library cuts it into batches of at most 2^27)
+                "paths_per_pass_per_rank": (args.width * ((args.height + world - 1) // world) * spp * min(world, args.steps)) if tiles
+                                           else args.width * args.height * spp,
             },
+            "reduce_ms": 1e3 * reduce_s if dist is not None else None,
+            "film_bytes": 24 * args.width * args.height,
             "samples_rendered": samples, "samples_expected": expected,
             "pipeline_hbm_fraction": rays / elapsed * PIPELINE_BYTES_PER_RAY / (HBM_PEAK_GBS * 1e9 * world),
             "nan_samples": int(c.nan_samples), "stack_overflows": int(c.stack_overflows), "medium_overflows": int(c.medium_overflows),
@@ -387,10 +449,19 @@ def main():
             if not tile_check["bit_identical"]:
                 print("bench.py: the gathered film differs from the rank-local re-render", file=sys.stderr)
                 rc = 1
+        # counters of the rocprofv3 PMC passes belong beside this run's timing only if they were taken on THIS build
         pmc = None
+        build = importlib.import_module("ray-tracing_amd.buildinfo").kernel_source_hash()
+        pmc_stale = None
         if os.path.exists(PMC_SUMMARY):
             with open(PMC_SUMMARY) as f:
                 pmc = json.load(f)
+            pmc_stale = pmc.get("build") != build
+            if pmc_stale:
+                print(f"bench.py: {PMC_SUMMARY} describes build {pmc.get('build')}, this tree is {build}: its counters are not printed", file=sys.stderr)
+                pmc = {"source": pmc.get("source"), "build": pmc.get("build")}
+        out["build"] = build
+        out["pmc_stale"] = pmc_stale
         if stages:
             ms, launches = stages["extend"]
             rays_per_launch = c.closest_rays / max(1, launches)
@@ -402,17 +473,26 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 # fabric bytes per launch from the PMC passes (TCC_EA0_RDREQ x 128 B + WRREQ 64 / 32 B), per ray x this run's rays per launch
                 "traffic": k["fabric_bytes_per_ray"] * rays_per_launch if k.get("fabric_bytes_per_ray") else None,
-                # what actually limits the kernel, not bytes: the L1 address path (four 16-byte requests per lane and node
-                # step; one request more costs 5.4 %, nine VALU instructions fewer cost nothing: DESIGN.md section 5) beside
-                # instruction issue under divergence (the PMC fractions that follow)
-                "limiter": "l1-requests+valu-issue", "valu_busy": k.get("valu_busy"), "lane_util": k.get("lane_util"), "ta_busy": k.get("ta_busy"),
-                "useful_issue_frac": (k["valu_busy"] * k["lane_util"]) if k.get("valu_busy") and k.get("lane_util") else None,
-                "pmc_source": (pmc or {}).get("source"), "pmc_batch_paths": (pmc or {}).get("batch_paths"),
+                "pmc_source": (pmc or {}).get("source"), "pmc_build": (pmc or {}).get("build"), "pmc_stale": pmc_stale,
+                "pmc_batch_paths": (pmc or {}).get("batch_paths"),
                 "avg_launch_us": avg_s * 1e6, "launches": int(launches), "rays_per_launch": rays_per_launch,
                 "algorithmic_bytes_per_ray": EXTEND_BYTES_PER_RAY,
                 "stage_ms": {k2: v[0] for k2, v in stages.items()},
             }
-        # VALU side of the roofline. Model flops: 25 per child-box slab test (4 per wide-node step),
+            # The same kernel against the roof that does bound it (VALU issue under divergence, beside the L1
+            # address path): model flops = 100 per 4-wide node step + 60 per primitive test, both counted on the device,
+            # over the same HIP-event launch time; beside it what the PMC passes of this build measured.
+            local_rays = max(1, int(c.closest_rays + c.shadow_rays))
+            trav_flops_per_ray = (100.0 * int(c.reserved[3]) + 60.0 * int(c.reserved[4])) / local_rays
+            achieved_tf = trav_flops_per_ray * rays_per_launch / avg_s / 1e12
+            out["roofline_valu"] = {
+                "kernel": out["roofline"]["kernel"], "bound": "valu", "achieved": achieved_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / VALU_PEAK_TFLOPS, "model_flops_per_ray": trav_flops_per_ray,
+                "valu_busy": k.get("valu_busy"), "lane_util": k.get("lane_util"), "ta_busy": k.get("ta_busy"),
+                "useful_issue_frac": (k["valu_busy"] * k["lane_util"]) if k.get("valu_busy") and k.get("lane_util") else None,
+                "pmc_stale": pmc_stale,
+            }
+        # VALU side of the whole pipeline. Model flops: 25 per child-box slab test (4 per wide-node step),
         # 60 per primitive test (both counted on the device), 300 per ray for its half of a bounce's shading.
         local_rays = max(1, int(c.closest_rays + c.shadow_rays))
         flops_per_ray = (100.0 * int(c.reserved[3]) + 60.0 * int(c.reserved[4])) / local_rays + 300.0
@@ -422,8 +502,8 @@ def main():
             "achieved": rays / elapsed * flops_per_ray / 1e12, "peak": VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
             "frac": rays / elapsed * flops_per_ray / 1e12 / (VALU_PEAK_TFLOPS * world),
             "pmc": {name: {f: v.get(f) for f in ("valu_busy", "lane_util", "ta_busy", "wait_frac", "fabric_bytes_per_ray", "avg_us")}
-                    for name, v in (pmc or {}).get("kernels", {}).items()} if pmc else None,
-            "pmc_source": (pmc or {}).get("source"),
+                    for name, v in (pmc or {}).get("kernels", {}).items()} if pmc and pmc.get("kernels") else None,
+            "pmc_source": (pmc or {}).get("source"), "pmc_stale": pmc_stale,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref_rgb, tile, ref_nan = cpu_baseline(S, A, args)

@@ -285,6 +285,7 @@ typedef struct fcgpu_counters {
                                    push is dropped, so the image is not valid: must stay 0 like stack_overflows
                                    (also in reserved[0])                                                          */
     uint64_t medium_deep_pushes;/* diagnostics: pushes that landed in entries 6..9 of that stack                  */
+    uint64_t reduce_bytes_copied;/* bytes the copies of fcgpu_reduce_film moved into this context (as root) so far  */
 } fcgpu_counters;
 
 /* per-stage device time, measured with HIP events on the context's stream around each launch
@@ -429,11 +430,15 @@ int fcgpu_film_device_ptr(fcgpu_ctx* ctx, void** rgb_dev, uint64_t* bytes);
 int fcgpu_add_sample_count(fcgpu_ctx* ctx, int64_t delta);
 /* Replaces the per-worker film sum of renderer::export_image (renderer.hpp:125-135) for one process that drives
  * several GPUs (one context per device): adds the films and sample counts of all `count` contexts into
- * ctxs[root] (peer copies over xGMI into a staging film on the root's device + one add kernel each; no host
- * round trip), then clears the other films and zeroes their sample counts, so that rendering more and reducing again
- * accumulates. All contexts must hold scenes of the same resolution. Synchronous; the caller must not be rendering
- * on any of the contexts from another thread. With disjoint pixel ownership (fcgpu_render_bands) the adds are
- * additions of zero: the result is bit-identical to one GPU's film. Errors are reported on ctxs[root]. */
+ * ctxs[root], then clears the other films and zeroes their sample counts, so that rendering more and reducing again
+ * accumulates. A contributor that has rendered only its bands (fcgpu_render_bands, one pattern since its last clear)
+ * sends only those rows, and all such contributors copy at once, each on its own stream, into disjoint rows of one
+ * staging film the root keeps (W*H*24 bytes on the root's device); a contributor that rendered anything else sends the
+ * whole frame. Copies between devices are direct peer accesses (hipDeviceEnablePeerAccess: xGMI) where the devices
+ * allow it, hipMemcpyPeerAsync otherwise; no host round trip of the library's own. fcgpu_counters.reduce_bytes_copied
+ * of the root counts what was moved. All contexts must hold scenes of the same resolution. Synchronous; the caller must
+ * not be rendering on any of the contexts from another thread. With disjoint pixel ownership the adds are additions
+ * of zero: the result is bit-identical to one GPU's film. Errors are reported on ctxs[root]. */
 int fcgpu_reduce_film(fcgpu_ctx* const* ctxs, int count, int root);
 
 int fcgpu_get_counters(fcgpu_ctx* ctx, fcgpu_counters* out);

@@ -123,7 +123,7 @@ class Counters(C.Structure):
         ("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
         ("shadow_occluded", C.c_uint64), ("nan_samples", C.c_uint64), ("stack_overflows", C.c_uint64),
         ("bvh_nodes", C.c_uint64), ("primitives", C.c_uint64), ("kernel_launches", C.c_uint64),
-        ("reserved", C.c_uint64 * 7), ("medium_overflows", C.c_uint64), ("medium_deep_pushes", C.c_uint64),
+        ("reserved", C.c_uint64 * 7), ("medium_overflows", C.c_uint64), ("medium_deep_pushes", C.c_uint64), ("reduce_bytes_copied", C.c_uint64),
     ]
 
 

@@ -55,6 +55,7 @@ struct fcgpu_ctx
     Wavefront<double> q64{}, q64b{};
     int slots{1};
     size_t stack_spill_words{};        // words of one batch slot's spill area
+    uint32_t stack_spill_entries{};    // entries per lane column of it
     uint32_t* stack_spill{};           // scene_allocs entry: traversal stack entries beyond STACK_CAP, per grid lane
     hipStream_t stream_b{};
     hipStream_t span_stream{};         // stream the next StageSpan records on
@@ -73,6 +74,17 @@ struct fcgpu_ctx
     uint32_t dec_bounces{};
     uint64_t dec_paths{};
     unsigned char* noalloc_scratch{};  // this device's copy of the static scratch array (fc_kernels.hip), set at create
+    // fcgpu_reduce_film: which film rows hold anything since the last clear (so that a contributor that rendered bands
+    // sends its bands, not the frame), the landing zone of the peer copies on a root, an event to order streams of
+    // different devices, and the bytes the copies moved
+    struct Coverage
+    {
+        bool any{}, banded{};
+        uint32_t rows{}, first{}, stride{1};
+    } cover;
+    double* reduce_staging{};
+    hipEvent_t ev_reduce{};
+    uint64_t reduce_bytes{};
     uint64_t samples{};
     uint64_t launches{};
     int grid{};
@@ -172,6 +184,7 @@ namespace
         S.env_kind = c->flat.env_kind;
         S.stack_spill = c->stack_spill;
         S.stack_spill_stride = static_cast<uint32_t>(c->grid) * 256u;
+        S.stack_spill_cap = c->stack_spill_entries;
         S.textured_materials = 0;
         for(const MaterialRec& m : c->flat.materials) S.textured_materials |= static_cast<uint32_t>(m.textured);
         S.envtex = EnvTex<R>{};
@@ -624,6 +637,17 @@ namespace
         HIP_TRY(c, hipSetDevice(c->device));
         int rc = ensure_queues(c, static_cast<uint64_t>(tile.w) * static_cast<uint64_t>(tile.h) * sample_count);
         if(rc) return rc;
+        // rows of the film this context has written since its last clear (fcgpu_reduce_film sends only those)
+        fcgpu_ctx::Coverage& cov = c->cover;
+        const bool same_bands = cov.banded && cov.rows == bands.rows && cov.first == bands.first && cov.stride == bands.stride;
+        cov.banded = bands.rows != 0 && (!cov.any || same_bands);
+        cov.any = true;
+        if(cov.banded)
+        {
+            cov.rows = bands.rows;
+            cov.first = bands.first;
+            cov.stride = bands.stride;
+        }
         if(c->opt.precision == FCGPU_PRECISION_F64)
             return run_batches(c, c->s64, c->q64, c->q64b, tile, bands, sample_begin, sample_count, integrator, max_path_length, visible_env);
         return run_batches(c, c->s32, c->q32, c->q32b, tile, bands, sample_begin, sample_count, integrator, max_path_length, visible_env);
@@ -725,7 +749,13 @@ extern "C"
         if((e = hipMalloc(reinterpret_cast<void**>(&c->stats), sizeof(unsigned long long) * ST_COUNT)) != hipSuccess) return bail(e, "hipMalloc");
         if((e = hipMemset(c->counters, 0, sizeof(QueueCounters))) != hipSuccess) return bail(e, "hipMemset");
         if((e = hipMemset(c->stats, 0, sizeof(unsigned long long) * ST_COUNT)) != hipSuccess) return bail(e, "hipMemset");
-        if((e = noalloc_scratch_for_device(device, &c->noalloc_scratch)) != hipSuccess) return bail(e, "hipGetSymbolAddress(scratch)");
+        // no scratch address (a device index beyond the table, a failed symbol lookup) only disables fcgpu_trace_closest_noalloc,
+        // which then reports it; every other entry point works without
+        if(noalloc_scratch_for_device(device, &c->noalloc_scratch) != hipSuccess)
+        {
+            c->noalloc_scratch = nullptr;
+            (void)hipGetLastError();
+        }
         hipDeviceProp_t prop{};
         if((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
         c->grid = std::max(1, prop.multiProcessorCount) * 8;
@@ -781,6 +811,8 @@ extern "C"
         free_pool(c->scene_allocs);
         free_pool(c->queue_allocs);
         if(c->film) (void)hipFree(c->film);
+        if(c->reduce_staging) (void)hipFree(c->reduce_staging);
+        if(c->ev_reduce) (void)hipEventDestroy(c->ev_reduce);
         if(c->dec_hit) (void)hipFree(c->dec_hit);
         if(c->dec_flags) (void)hipFree(c->dec_flags);
         (void)hipFree(c->counters);
@@ -855,6 +887,7 @@ extern "C"
 
             c->stack_spill = nullptr;
             c->stack_spill_words = 0;
+            c->stack_spill_entries = 0;
             // The kernels without spill code stop pushing once fewer than three free LDS entries are left (one test per
             // node step instead of one per push), which is exact only while the worst case is <= STACK_CAP - 2: any
             // deeper hierarchy, including the ones that would just fit, runs the SPILL instantiations.
@@ -864,6 +897,7 @@ extern "C"
                 // one column per lane of the persistent grid (and per batch slot)
                 void* p = nullptr;
                 const size_t entries = c->flat.max_stack > static_cast<uint32_t>(STACK_CAP) ? c->flat.max_stack - static_cast<uint32_t>(STACK_CAP) : 1u;
+                c->stack_spill_entries = static_cast<uint32_t>(entries);
                 c->stack_spill_words = entries * static_cast<size_t>(c->grid) * 256u;
                 HIP_TRY(c, hipMalloc(&p, c->stack_spill_words * sizeof(uint32_t) * static_cast<size_t>(c->slots)));
                 c->scene_allocs.push_back(p);
@@ -895,6 +929,9 @@ extern "C"
             c->film_elems = 3ull * static_cast<uint64_t>(c->flat.width) * static_cast<uint64_t>(c->flat.height);
             HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->film), sizeof(double) * c->film_elems));
             HIP_TRY(c, hipMemset(c->film, 0, sizeof(double) * c->film_elems));
+            if(c->reduce_staging) (void)hipFree(c->reduce_staging);  // sized to the previous film
+            c->reduce_staging = nullptr;
+            c->cover = fcgpu_ctx::Coverage{};
             c->samples = 0;
             c->has_scene = true;
             return FCGPU_OK;
@@ -978,6 +1015,7 @@ extern "C"
             S.epsilon = static_cast<decltype(S.epsilon)>(effective_epsilon(c));
             S.stack_spill = deep ? reinterpret_cast<uint32_t*>(c->noalloc_scratch + NOALLOC_STATS_BYTES) : nullptr;
             S.stack_spill_stride = NOALLOC_LANES;
+            S.stack_spill_cap = NOALLOC_SPILL_ENTRIES;  // the static array's columns, not the context's own spill area
             launch_trace(L, S, n, rays_dev, hits_dev, static_cast<uint8_t*>(nullptr), stats);
         };
         if(c->opt.precision == FCGPU_PRECISION_F64)
@@ -1016,6 +1054,11 @@ extern "C"
     }
 
     // ------------------------------------------------------------------ multi-GPU film reduce (renderer.hpp:125-135)
+    // Contributors whose film holds only their bands (fcgpu_render_bands with one pattern since the last clear) send those
+    // rows, all at once: their copies run on their own streams into disjoint rows of one staging film on the root's
+    // device, each followed by an add over just those rows. Contributors that rendered anything else send the frame, one
+    // after the other through the same staging film. Between different devices the copies are direct peer accesses
+    // (hipDeviceEnablePeerAccess: xGMI on an MI355X node) where the devices allow it, hipMemcpyPeerAsync otherwise.
     int fcgpu_reduce_film(fcgpu_ctx* const* ctxs, int count, int root)
     {
         fcgpu_ctx* r = (ctxs && count > 0 && root >= 0 && root < count) ? ctxs[root] : nullptr;
@@ -1031,43 +1074,134 @@ extern "C"
             }
             if(count == 1) return FCGPU_OK;
             const size_t bytes = sizeof(double) * r->film_elems;
+            const uint64_t H = static_cast<uint64_t>(r->flat.height), row_elems = 3ull * static_cast<uint64_t>(r->flat.width);
+            const size_t row_bytes = sizeof(double) * row_elems;
             // every contributor has finished rendering before its film is read
             for(int i = 0; i < count; ++i)
             {
-                HIP_TRY(r, hipSetDevice(ctxs[i]->device));
-                HIP_TRY(r, hipStreamSynchronize(ctxs[i]->stream));
-                if(ctxs[i]->stream_b) HIP_TRY(r, hipStreamSynchronize(ctxs[i]->stream_b));
+                fcgpu_ctx* s = ctxs[i];
+                HIP_TRY(r, hipSetDevice(s->device));
+                HIP_TRY(r, hipStreamSynchronize(s->stream));
+                if(s->stream_b) HIP_TRY(r, hipStreamSynchronize(s->stream_b));
+                if(!s->ev_reduce) HIP_TRY(r, hipEventCreateWithFlags(&s->ev_reduce, hipEventDisableTiming));
+            }
+            // direct access from each contributor's device to the root's memory (the copy runs on the contributor's stream)
+            std::vector<char> peer(static_cast<size_t>(count), 1);
+            for(int i = 0; i < count; ++i)
+            {
+                fcgpu_ctx* s = ctxs[i];
+                if(i == root || s->device == r->device) continue;
+                int can = 0;
+                HIP_TRY(r, hipDeviceCanAccessPeer(&can, s->device, r->device));
+                peer[static_cast<size_t>(i)] = 0;
+                if(!can) continue;
+                HIP_TRY(r, hipSetDevice(s->device));
+                const hipError_t e = hipDeviceEnablePeerAccess(r->device, 0);
+                if(e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled)
+                    peer[static_cast<size_t>(i)] = 1;
+                (void)hipGetLastError();
             }
             HIP_TRY(r, hipSetDevice(r->device));
-            void* staging = nullptr;  // one film on the root's device: the landing zone of the peer copies (xGMI between GPUs)
-            HIP_TRY(r, hipMalloc(&staging, bytes));
-            int rc = FCGPU_OK;
-            for(int i = 0; i < count && rc == FCGPU_OK; ++i)
+            if(!r->reduce_staging) HIP_TRY(r, hipMalloc(reinterpret_cast<void**>(&r->reduce_staging), bytes));  // kept: the next reduce reuses it
+            double* staging = r->reduce_staging;
+
+            // copy of `n` bytes at the same offset of two films, on the contributor's stream
+            auto copy = [&](fcgpu_ctx* s, bool direct, uint64_t elem_off, size_t n) -> hipError_t
+            {
+                r->reduce_bytes += n;
+                if(direct) return hipMemcpyAsync(staging + elem_off, s->film + elem_off, n, hipMemcpyDeviceToDevice, s->stream);
+                return hipMemcpyPeerAsync(staging + elem_off, r->device, s->film + elem_off, s->device, n, s->stream);
+            };
+            // banded contributors that can go together: one band pattern (rows, stride), distinct `first`
+            std::vector<int> together, alone;
+            for(int i = 0; i < count; ++i)
             {
                 if(i == root) continue;
+                const fcgpu_ctx::Coverage& c = ctxs[i]->cover;
+                if(!c.any) continue;  // rendered nothing since its last clear: only its sample count (0) counts
+                bool ok = c.banded;
+                for(int j : together)
+                    ok = ok && ctxs[j]->cover.rows == c.rows && ctxs[j]->cover.stride == c.stride && ctxs[j]->cover.first != c.first;
+                (ok ? together : alone).push_back(i);
+            }
+            int rc = FCGPU_OK;
+            auto check = [&](hipError_t e, const char* what)
+            {
+                if(e != hipSuccess && rc == FCGPU_OK) rc = hip_fail(r, e, what);
+                return e == hipSuccess;
+            };
+            for(int i : together)
+            {
+                fcgpu_ctx* s = ctxs[static_cast<size_t>(i)];
+                const fcgpu_ctx::Coverage& c = s->cover;
+                const bool direct = s->device == r->device || peer[static_cast<size_t>(i)];
+                if(!check(hipSetDevice(s->device), "hipSetDevice")) break;
+                const uint64_t period = static_cast<uint64_t>(c.stride) * c.rows;
+                uint64_t owned_rows = 0, full_bands = 0, tail_y = 0, tail_rows = 0;
+                for(uint64_t y0 = static_cast<uint64_t>(c.first) * c.rows; y0 < H; y0 += period)
+                {
+                    const uint64_t n = std::min<uint64_t>(c.rows, H - y0);
+                    owned_rows += n;
+                    if(n == c.rows)
+                        full_bands += 1;
+                    else
+                    {
+                        tail_y = y0;
+                        tail_rows = n;
+                    }
+                }
+                const uint64_t first_off = static_cast<uint64_t>(c.first) * c.rows * row_elems;
+                bool ok = true;
+                if(direct && full_bands > 0)
+                {
+                    // all whole bands of this contributor in one strided copy
+                    r->reduce_bytes += full_bands * c.rows * row_bytes;
+                    ok = check(hipMemcpy2DAsync(staging + first_off, period * row_bytes, s->film + first_off, period * row_bytes, c.rows * row_bytes,
+                                                full_bands, hipMemcpyDeviceToDevice, s->stream), "film band copy");
+                }
+                else
+                {
+                    for(uint64_t b = 0; b < full_bands && ok; ++b) ok = check(copy(s, false, first_off + b * period * row_elems, c.rows * row_bytes), "film band copy");
+                }
+                if(ok && tail_rows) ok = check(copy(s, direct, tail_y * row_elems, tail_rows * row_bytes), "film band copy");
+                if(!ok) break;
+                check(hipEventRecord(s->ev_reduce, s->stream), "hipEventRecord");
+                check(hipMemsetAsync(s->film, 0, bytes, s->stream), "film clear");  // after its copy, in stream order
+                if(!check(hipSetDevice(r->device), "hipSetDevice")) break;
+                check(hipStreamWaitEvent(r->stream, s->ev_reduce, 0), "hipStreamWaitEvent");
+                launch_film_add_bands(LaunchCfg{r->stream, r->grid}, r->film, staging, row_elems, owned_rows, c.rows, c.first, c.stride);
+            }
+            for(int i : alone)
+            {
+                if(rc != FCGPU_OK) break;
+                fcgpu_ctx* s = ctxs[static_cast<size_t>(i)];
+                const bool direct = s->device == r->device || peer[static_cast<size_t>(i)];
+                // the staging film is free once the root's previous add has run
+                if(!check(hipSetDevice(r->device), "hipSetDevice")) break;
+                check(hipEventRecord(r->ev_reduce, r->stream), "hipEventRecord");
+                if(!check(hipSetDevice(s->device), "hipSetDevice")) break;
+                check(hipStreamWaitEvent(s->stream, r->ev_reduce, 0), "hipStreamWaitEvent");
+                if(!check(copy(s, direct, 0, bytes), "film copy")) break;
+                check(hipEventRecord(s->ev_reduce, s->stream), "hipEventRecord");
+                check(hipMemsetAsync(s->film, 0, bytes, s->stream), "film clear");
+                if(!check(hipSetDevice(r->device), "hipSetDevice")) break;
+                check(hipStreamWaitEvent(r->stream, s->ev_reduce, 0), "hipStreamWaitEvent");
+                launch_film_add(LaunchCfg{r->stream, r->grid}, r->film, staging, r->film_elems);
+            }
+            // everything has landed before the call returns; the contributors start over: a later render + reduce adds only what is new
+            for(int i = 0; i < count; ++i)
+            {
                 fcgpu_ctx* s = ctxs[i];
-                hipError_t e = s->device == r->device ? hipMemcpyAsync(staging, s->film, bytes, hipMemcpyDeviceToDevice, r->stream)
-                                                      : hipMemcpyPeerAsync(staging, r->device, s->film, s->device, bytes, r->stream);
-                if(e != hipSuccess)
-                {
-                    rc = hip_fail(r, e, "film peer copy");
-                    break;
-                }
-                launch_film_add(LaunchCfg{r->stream, r->grid}, r->film, static_cast<const double*>(staging), r->film_elems);
-                if((e = hipStreamSynchronize(r->stream)) != hipSuccess)
-                {
-                    rc = hip_fail(r, e, "film add");
-                    break;
-                }
-                // the contributor starts over: a later render + reduce adds only what is new
+                if(hipSetDevice(s->device) == hipSuccess) check(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+                if(i == root || rc != FCGPU_OK) continue;
                 r->samples += s->samples;
                 s->samples = 0;
-                if((e = hipSetDevice(s->device)) != hipSuccess || (e = hipMemsetAsync(s->film, 0, bytes, s->stream)) != hipSuccess ||
-                   (e = hipStreamSynchronize(s->stream)) != hipSuccess)
-                    rc = hip_fail(r, e, "film clear");
-                (void)hipSetDevice(r->device);
+                s->cover = fcgpu_ctx::Coverage{};
             }
-            (void)hipFree(staging);
+            (void)hipSetDevice(r->device);
+            check(hipGetLastError(), "film add launch");
+            r->cover.any = true;
+            r->cover.banded = false;  // the root's film now holds rows of every contributor
             return rc;
         });
     }
@@ -1136,6 +1270,7 @@ extern "C"
             HIP_TRY(c, hipSetDevice(c->device));
             HIP_TRY(c, hipMemsetAsync(c->film, 0, sizeof(double) * c->film_elems, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->cover = fcgpu_ctx::Coverage{};
             c->samples = 0;
             return FCGPU_OK;
         });
@@ -1203,6 +1338,7 @@ extern "C"
             out->reserved[6] = c->flatten_us;
             out->medium_overflows = st[ST_MEDIUM_OVERFLOW];
             out->medium_deep_pushes = st[ST_MEDIUM_DEEP];
+            out->reduce_bytes_copied = c->reduce_bytes;
             return FCGPU_OK;
         });
     }

@@ -55,6 +55,8 @@ namespace fcg
 
     // dst[i] += src[i] over the film of the root context (fcgpu_reduce_film)
     void launch_film_add(const LaunchCfg& L, double* dst, const double* src, uint64_t n);
+    void launch_film_add_bands(const LaunchCfg& L, double* dst, const double* src, uint64_t row_elems, uint64_t owned_rows, uint32_t rows,
+                               uint32_t first, uint32_t stride);
     // frame = ng, tangent, ns, bitangent (3 doubles each); device pointers (fcgpu_bsdf_table)
     template<typename R>
     void launch_bsdf_table(const LaunchCfg& L, const LobeRec<R>* lobes, int lobe_count, const double* frame, double eta_a, double eta_b, uint64_t n,

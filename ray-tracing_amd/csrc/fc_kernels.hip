@@ -1261,7 +1261,9 @@ namespace fcg
 
     hipError_t noalloc_scratch_for_device(int device, unsigned char** out)
     {
-        constexpr int MAX_DEVICES = 64;
+        constexpr int MAX_DEVICES = 64;  // beyond it: no scratch address, i.e. no fcgpu_trace_closest_noalloc on that device (everything else works)
+        static_assert(STACK_CAP + static_cast<int>(NOALLOC_SPILL_ENTRIES) == FCGPU_NOALLOC_MAX_STACK, "include/fcgpu.h states the limit the kernel has");
+        static_assert(static_cast<int>(NOALLOC_SPILL_ENTRIES) <= STACK_SPILL_MAX, "the kernel bounds spill pushes by STACK_SPILL_MAX: the static columns must hold that many");
         static std::mutex lock;
         static unsigned char* address[MAX_DEVICES] = {};
         *out = nullptr;
@@ -1297,6 +1299,24 @@ namespace fcg
     void launch_film_add(const LaunchCfg& L, double* dst, const double* src, uint64_t n)
     {
         hipLaunchKernelGGL(k_film_add, dim3(L.grid), dim3(BLOCK), 0, L.stream, dst, src, n);
+    }
+    // the same over the rows of the bands b = first, first + stride, ... of `rows` film rows (row_elems doubles per row)
+    __global__ __launch_bounds__(BLOCK) void k_film_add_bands(double* dst, const double* src, uint64_t row_elems, uint64_t owned_rows, uint32_t rows,
+                                                              uint32_t first, uint32_t stride)
+    {
+        const uint64_t n = owned_rows * row_elems;
+        for(uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * BLOCK)
+        {
+            const uint64_t r = i / row_elems, band = r / rows;
+            const uint64_t y = (first + band * stride) * rows + (r - band * rows);
+            const uint64_t off = y * row_elems + (i - r * row_elems);
+            dst[off] += src[off];
+        }
+    }
+    void launch_film_add_bands(const LaunchCfg& L, double* dst, const double* src, uint64_t row_elems, uint64_t owned_rows, uint32_t rows,
+                               uint32_t first, uint32_t stride)
+    {
+        hipLaunchKernelGGL(k_film_add_bands, dim3(L.grid), dim3(BLOCK), 0, L.stream, dst, src, row_elems, owned_rows, rows, first, stride);
     }
 #endif
 

@@ -211,7 +211,7 @@ namespace fcg
     // is what min/max of the two plane distances would give.
     template<typename R, bool ANY, int STRIDE, bool SPILL>
     FC_D uint32_t node_step(const RayCtx<R>& rc, R t_max, uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint32_t* stack, uint32_t* spill,
-                            uint32_t spill_stride, int& sp, StackStats& overflow, bool& lost_push)
+                            uint32_t spill_stride, int spill_cap, int& sp, StackStats& overflow, bool& lost_push)
     {
         R ox = R(__builtin_bit_cast(float, n0.x)), oy = R(__builtin_bit_cast(float, n0.y)), oz = R(__builtin_bit_cast(float, n0.z));
         R ax = R(__builtin_bit_cast(float, n0.w)) * rc.inv_d.x;  // grid steps: powers of two (Node4::sx, sy, sz)
@@ -266,14 +266,14 @@ namespace fcg
                 {
                     if(sp < STACK_CAP)
                         stack[sp * STRIDE] = ch[k];
-                    else if(sp < STACK_CAP + STACK_SPILL_MAX)
+                    else if(sp < STACK_CAP + spill_cap)  // spill_cap: entries of the column actually supplied (SceneDev::stack_spill_cap)
                     {
                         spill[static_cast<size_t>(sp - STACK_CAP) * spill_stride] = ch[k];
                         overflow.spilled += 1;
                     }
                     else
                         overflow.lost += 1;
-                    sp += sp < STACK_CAP + STACK_SPILL_MAX ? 1 : 0;
+                    sp += sp < STACK_CAP + spill_cap ? 1 : 0;
                 }
             }
         }
@@ -403,7 +403,7 @@ namespace fcg
 #else
                 const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
 #endif
-                uint32_t next = node_step<R, ANY, STRIDE, SPILL>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, sp, overflow, lost_push);
+                uint32_t next = node_step<R, ANY, STRIDE, SPILL>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, static_cast<int>(S.stack_spill_cap), sp, overflow, lost_push);
                 if(PROF) n_nodes += 1;  // per lane (the timeline wants the lane maximum); otherwise per wave, below
                 if(PROF && next == INVALID_U32)
                 {
@@ -414,7 +414,7 @@ namespace fcg
                     StackStats dummy;
                     bool dummy_lost = false;
                     if(!SPILL && sp <= STACK_CAP - 3 &&
-                       node_step<R, ANY, STRIDE, SPILL>(T.rc, consts<R>::inf, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, sp2, dummy, dummy_lost) != INVALID_U32)
+                       node_step<R, ANY, STRIDE, SPILL>(T.rc, consts<R>::inf, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, static_cast<int>(S.stack_spill_cap), sp2, dummy, dummy_lost) != INVALID_U32)
                         ph[12] += 1;
                 }
                 if(next == INVALID_U32 && sp > 0) next = stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp);

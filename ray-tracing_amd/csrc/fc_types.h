@@ -242,6 +242,7 @@ namespace fcg
         const TriShade<R>* tri_shade;  // by triangle index
         uint32_t* stack_spill;     // [depth - STACK_CAP][grid lanes] or nullptr when the BVH fits the LDS stack
         uint32_t stack_spill_stride;
+        uint32_t stack_spill_cap;  // entries per lane column of stack_spill: pushes beyond STACK_CAP + this are counted as lost
         uint32_t textured_materials;  // 1 = some material has image textures (selects the TEX kernel instantiations)
         CameraRec<R> camera;
         uint32_t light_count;

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(A.Entity) == 16 + 4 * 8
     assert C.sizeof(A.Camera) == 9 * 8 + 8
     assert C.sizeof(A.Ray) == 56 and C.sizeof(A.Hit) == 32
-    assert C.sizeof(A.Counters) == 18 * 8
+    assert C.sizeof(A.Counters) == 19 * 8
     assert C.sizeof(A.Options) == 32
 
 

@@ -31,7 +31,11 @@ def test_bench_line_single_gpu_tiles():
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["unit"] == "Mrays/s" and d["value"] > 0
     assert d["samples_rendered"] == d["samples_expected"] == 480 * 270 * 4 * 2
     assert d["tile_check"]["bit_identical"] and d["tile_check"]["rows"] > 0
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["limiter"] == "l1-requests+valu-issue"
+    # two rooflines of the dominant kernel: the bytes roof the contract names and the VALU roof that binds
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["unit"] == "GB/s"
+    assert d["roofline_valu"]["bound"] == "valu" and 0 < d["roofline_valu"]["frac"] < 1 and d["roofline_valu"]["unit"] == "TFLOP/s"
+    # counters of the PMC passes are printed only when they were taken on this build, and the line says which it is
+    assert d["pmc_stale"] in (True, False, None) and (d["roofline"]["traffic"] is None) == (d["pmc_stale"] is not False)
     assert d["stack_overflows"] == 0 and d["nan_samples"] == 0
 
 
@@ -43,6 +47,9 @@ def test_bench_starts_its_own_ranks(shard):
     per_job = 480 * 270 * 4 * 2
     assert d["samples_rendered"] == d["samples_expected"] == (per_job if shard == "tiles" else 2 * per_job)
     assert d["scaling"] == ("strong" if shard == "tiles" else "weak")
+    assert d["reduce_ms"] is not None and d["reduce_ms"] >= 0 and d["film_bytes"] == 24 * 480 * 270
     if shard == "tiles":
+        # a rank takes the samples of `world` steps per pass, so that its batch is as large as a single GPU's
+        assert d["config"]["paths_per_pass_per_rank"] == 480 * 135 * 4 * 2
         t = d["tile_check"]
         assert t["bit_identical"] and all(o == 1 for o in t["owners"])  # bands of the OTHER rank, re-rendered by rank 0

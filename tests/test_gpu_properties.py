@@ -456,12 +456,16 @@ def test_band_sharding_is_bit_exact_and_reduces_in_the_library():
         R.reduce_film(ctxs, root=1)
         rgb, cnt = ctxs[1].read_film()
         rays = sum(int(c.counters().closest_rays) for c in ctxs)
+        copied = int(ctxs[1].counters().reduce_bytes_copied)
         others = [c.read_film() for i, c in enumerate(ctxs) if i != 1]
         for c in ctxs:
             c.close()
         assert cnt == n and np.array_equal(rgb, full), (band_rows, world)
         assert rays == int(cf.closest_rays)
         assert all(k == 0 and a.max() == 0 for a, k in others)  # contributors start over after a reduce
+        # a contributor that rendered bands sends its bands, not the frame: the copies moved exactly the rows the other ranks own
+        rows_of = lambda rank: sum(min(band_rows, 75 - y0) for y0 in range(rank * band_rows, 75, world * band_rows))
+        assert copied == sum(rows_of(k) for k in range(world) if k != 1) * 200 * 24, (band_rows, world, copied)
 
 
 def test_reduce_film_sums_sample_passes():
@@ -479,6 +483,7 @@ def test_reduce_film_sums_sample_passes():
         ctxs.append(ctx)
     R.reduce_film(ctxs, root=0)
     rgb, cnt = ctxs[0].read_film()
+    assert int(ctxs[0].counters().reduce_bytes_copied) == 96 * 54 * 24  # a contributor that rendered the frame sends the frame
     with pytest.raises(R.FcgpuError) as e:
         R.reduce_film([ctxs[0], ctxs[0]], root=0)
     assert e.value.code == A.E_INVALID

@@ -5,7 +5,8 @@ Formulas: kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; VALU b
 / kernel cycles; lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); TA busy = TA_TA_BUSY_sum / 256 CUs
 / kernel cycles; fabric bytes = TCC_EA0_RDREQ * 128 (all requests are 128-byte on this part: RDREQ_32B is 0) +
 TCC_EA0_WRREQ_64B * 64 + (TCC_EA0_WRREQ - WRREQ_64B) * 32."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, importlib, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 out, source, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
 # one rocprofv3 run per counter set: keep the sets apart (GRBM_GUI_ACTIVE is collected in two of them)
@@ -39,4 +40,6 @@ for k, (short, unit) in names.items():
             e["fabric_bytes_per_ray"] = b / rays[unit]
     if e:
         kern[short] = e
-print(json.dumps({"source": source, "batch_paths": batch, "rays": rays, "kernels": kern}, indent=1))
+# the counters describe the kernels of THIS tree: bench.py refuses to print them beside the timing of another build
+build = importlib.import_module("ray-tracing_amd.buildinfo").kernel_source_hash()
+print(json.dumps({"source": source, "build": build, "batch_paths": batch, "rays": rays, "kernels": kern}, indent=1))
