@@ -225,6 +225,7 @@ typedef struct fcgpu_scene_desc {
 #define FCGPU_BVH_HOST_SAH 0
 #define FCGPU_BVH_DEVICE_LBVH 1
 #define FCGPU_BVH_HOST_REFERENCE 2
+#define FCGPU_BVH_WIDE8 0x100       /* fcgpu_check_scene only: OR into its bvh_builder to flatten 8-wide (fcgpu_options.bvh_width = 8) */
 
 /* entity_scene::raycast / visibility lift a ray's origin `epsilon` off its surface along the geometric normal
  * (scene.hpp:85-93, 118-131, 146-152). NORMAL does exactly that. ALONG_RAY advances the origin along the ray until
@@ -246,7 +247,9 @@ typedef struct fcgpu_options {
                                    FCGPU_E_NOMEM is returned */
     uint32_t bvh_builder;       /* FCGPU_BVH_* */
     uint32_t origin_offset;     /* FCGPU_OFFSET_*: how a ray's origin leaves the surface it starts on */
-    uint32_t reserved;
+    uint32_t bvh_width;         /* children per node of the flattened hierarchy: 0 or 4 = the 4-wide 64-byte node (default),
+                                   8 = the 8-wide 80-byte node with octant-ordered child slots (measured slower on
+                                   MI355X: DESIGN.md section 5; hierarchies deeper than 15 levels are refused) */
 } fcgpu_options;
 
 typedef struct fcgpu_tile {
@@ -459,7 +462,8 @@ int fcgpu_export_image(fcgpu_ctx* ctx, const char* name);
 /* Validates a scene description and builds its hierarchy on the host without touching a device: what the
  * entity_scene constructor and bvh_acceleration_structure's build (bvh_acceleration_structure.hpp:10-24) do for the
  * reference, as far as it can fail or be measured before rendering. `bvh_builder`: FCGPU_BVH_HOST_SAH or
- * FCGPU_BVH_HOST_REFERENCE. On failure the message is fcgpu_last_error(NULL) of the calling thread.            */
+ * FCGPU_BVH_HOST_REFERENCE, optionally | FCGPU_BVH_WIDE8 (then wide_nodes counts 8-wide nodes and max_stack the group
+ * entries their traversal needs). On failure the message is fcgpu_last_error(NULL) of the calling thread.        */
 typedef struct fcgpu_scene_stats {
     uint64_t primitives, triangles;
     uint64_t binary_nodes, wide_nodes;

@@ -17,6 +17,7 @@ INTEGRATOR_BSDF, INTEGRATOR_MIS = 0, 1
 BVH_HOST_SAH, BVH_DEVICE_LBVH, BVH_HOST_REFERENCE = 0, 1, 2
 OFFSET_DEFAULT, OFFSET_NORMAL, OFFSET_ALONG_RAY = 0, 1, 2
 
+BVH_WIDE8 = 0x100
 E_INVALID, E_HIP, E_NOSCENE, E_LIMIT, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
 
@@ -101,7 +102,7 @@ class Options(C.Structure):
     _fields_ = [
         ("precision", C.c_int32), ("sort_materials", C.c_int32), ("epsilon", C.c_double),
         ("max_paths_in_flight", C.c_uint32), ("bvh_builder", C.c_uint32),
-        ("origin_offset", C.c_uint32), ("reserved", C.c_uint32),
+        ("origin_offset", C.c_uint32), ("bvh_width", C.c_uint32),
     ]
 
 

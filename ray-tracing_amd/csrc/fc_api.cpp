@@ -185,6 +185,7 @@ namespace
         S.stack_spill = c->stack_spill;
         S.stack_spill_stride = static_cast<uint32_t>(c->grid) * 256u;
         S.stack_spill_cap = c->stack_spill_entries;
+        S.node_count = static_cast<uint32_t>(c->flat.nodes.size());
         S.textured_materials = 0;
         for(const MaterialRec& m : c->flat.materials) S.textured_materials |= static_cast<uint32_t>(m.textured);
         S.envtex = EnvTex<R>{};
@@ -662,6 +663,8 @@ extern "C"
     {
         try
         {
+            const bool wide8 = (bvh_builder & FCGPU_BVH_WIDE8) != 0;
+            bvh_builder &= ~static_cast<uint32_t>(FCGPU_BVH_WIDE8);
             if(!d || (bvh_builder != FCGPU_BVH_HOST_SAH && bvh_builder != FCGPU_BVH_HOST_REFERENCE))
             {
                 g_create_error = d ? "fcgpu_check_scene builds on the host: FCGPU_BVH_HOST_SAH or FCGPU_BVH_HOST_REFERENCE" : "null scene";
@@ -669,7 +672,7 @@ extern "C"
             }
             FlatScene flat;
             std::string err;
-            const int rc = flatten_scene(*d, flat, err, nullptr, bvh_builder == FCGPU_BVH_HOST_REFERENCE);
+            const int rc = flatten_scene(*d, flat, err, nullptr, bvh_builder == FCGPU_BVH_HOST_REFERENCE, wide8 ? 8 : 4);
             if(rc != FCGPU_OK)
             {
                 g_create_error = err;
@@ -681,7 +684,7 @@ extern "C"
                 out->primitives = flat.prim_info.size();
                 out->triangles = flat.tris.size();
                 out->binary_nodes = flat.binary_nodes;
-                out->wide_nodes = flat.nodes.size();
+                out->wide_nodes = wide8 ? flat.nodes8.size() : flat.nodes.size();
                 out->max_stack = flat.max_stack;
                 out->lobe_mask = flat.lobe_mask;
             }
@@ -838,6 +841,7 @@ extern "C"
             if(opt->precision != FCGPU_PRECISION_F32 && opt->precision != FCGPU_PRECISION_F64) return fail(c, FCGPU_E_INVALID, "unknown precision");
             if(opt->max_paths_in_flight != 0 && opt->max_paths_in_flight < 256) return fail(c, FCGPU_E_INVALID, "max_paths_in_flight < 256");
             if(opt->bvh_builder > FCGPU_BVH_HOST_REFERENCE) return fail(c, FCGPU_E_INVALID, "unknown bvh_builder");
+            if(opt->bvh_width != 0 && opt->bvh_width != 4 && opt->bvh_width != 8) return fail(c, FCGPU_E_INVALID, "bvh_width must be 0 (default), 4 or 8");
             if(opt->origin_offset > FCGPU_OFFSET_ALONG_RAY) return fail(c, FCGPU_E_INVALID, "unknown origin_offset");
             if(opt->sort_materials != 1) return fail(c, FCGPU_E_UNSUPPORTED, "sort_materials must be 1: the shade kernels are one instantiation per lobe type");
             c->opt = *opt;
@@ -873,8 +877,14 @@ extern "C"
                 return lbvh_build(c->stream, boxes, tree, e);
             };
             const auto t_build = std::chrono::steady_clock::now();
+            const int width = c->opt.bvh_width == 8 ? 8 : 4;
             int rc = flatten_scene(*d, flat, err, c->opt.bvh_builder == FCGPU_BVH_DEVICE_LBVH ? &on_device : nullptr,
-                                   c->opt.bvh_builder == FCGPU_BVH_HOST_REFERENCE);
+                                   c->opt.bvh_builder == FCGPU_BVH_HOST_REFERENCE, width);
+            if(rc == FCGPU_OK && width == 8 && flat.max_stack > static_cast<uint32_t>(STACK8_CAP))
+            {
+                rc = FCGPU_E_LIMIT;
+                err = "bvh_width 8: the hierarchy needs more than " + std::to_string(STACK8_CAP) + " group entries on the traversal stack; use bvh_width 4";
+            }
             c->flatten_us = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_build).count());
             if(rc != FCGPU_OK) return fail(c, rc, err);
 
@@ -891,7 +901,7 @@ extern "C"
             // The kernels without spill code stop pushing once fewer than three free LDS entries are left (one test per
             // node step instead of one per push), which is exact only while the worst case is <= STACK_CAP - 2: any
             // deeper hierarchy, including the ones that would just fit, runs the SPILL instantiations.
-            if(c->flat.max_stack > static_cast<uint32_t>(STACK_CAP - 2))
+            if(width == 4 && c->flat.max_stack > static_cast<uint32_t>(STACK_CAP - 2))
             {
                 // deep BVH: the part of the worst-case stack beyond the LDS entries lives in global memory,
                 // one column per lane of the persistent grid (and per batch slot)
@@ -905,6 +915,7 @@ extern "C"
             }
             SceneDev<float> a{};
             if((rc = upload(c, c->scene_allocs, c->flat.nodes, &a.nodes))) return rc;
+            if(width == 8 && (rc = upload(c, c->scene_allocs, c->flat.nodes8, &a.nodes8))) return rc;
             if((rc = upload(c, c->scene_allocs, c->flat.tris, &a.tris))) return rc;
             if((rc = upload(c, c->scene_allocs, c->flat.tri_attrs, &a.tri_attrs))) return rc;
             if((rc = upload(c, c->scene_allocs, c->flat.prim_info, &a.prim_info))) return rc;
@@ -913,6 +924,7 @@ extern "C"
             if((rc = upload(c, c->scene_allocs, c->flat.light_cdf, &a.light_cdf))) return rc;
             SceneDev<double> b{};
             b.nodes = a.nodes;
+            b.nodes8 = a.nodes8;
             b.tris = a.tris;
             b.tri_attrs = a.tri_attrs;
             b.prim_info = a.prim_info;
@@ -1326,7 +1338,7 @@ extern "C"
             out->shadow_occluded = st[ST_OCCLUDED];
             out->nan_samples = st[ST_NAN];
             out->stack_overflows = st[ST_STACK_OVERFLOW];
-            out->bvh_nodes = c->flat.nodes.size();
+            out->bvh_nodes = c->flat.nodes8.empty() ? c->flat.nodes.size() : c->flat.nodes8.size();
             out->primitives = c->flat.prim_info.size();
             out->kernel_launches = c->launches;
             out->reserved[0] = st[ST_MEDIUM_OVERFLOW];

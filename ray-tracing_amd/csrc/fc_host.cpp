@@ -525,10 +525,15 @@ namespace fcg
         {
         public:
             // order_box[k] / order_ki[k]: bounds and kind|index of the k-th primitive in binary leaf order
-            WideBuilder(const BinaryBvh& bin, const std::vector<BoxF>& order_box, const std::vector<uint32_t>& order_ki, FlatScene& out)
-                : bin_{bin}, order_box_{order_box}, order_ki_{order_ki}, out_{out}
+            WideBuilder(const BinaryBvh& bin, const std::vector<BoxF>& order_box, const std::vector<uint32_t>& order_ki, FlatScene& out, int width = 4)
+                : bin_{bin}, order_box_{order_box}, order_ki_{order_ki}, out_{out}, width_{static_cast<size_t>(width)}
             {
             }
+
+            // 8-wide: the triangle records in the order the nodes reference them (indices into the leaf-ordered array the
+            // builder was given; a sphere / plane leaf is XPRIM_PROXY | kind << 24 | its xprims index)
+            std::vector<uint32_t> tri_order8;
+            std::string error;
 
             void run()
             {
@@ -554,7 +559,14 @@ namespace fcg
                 }
                 std::vector<WideChild> kids;
                 gather(0, kids);
-                out_.max_stack = emit(kids);
+                if(width_ == 8)
+                {
+                    out_.nodes8.assign(1, Node8{});
+                    out_.max_stack = emit8(0, kids);
+                    if(out_.nodes8.size() > NODE8_MAX_NODES) error = "8-wide hierarchy: more than 2^24 nodes";
+                }
+                else
+                    out_.max_stack = emit(kids);
             }
 
         private:
@@ -564,6 +576,7 @@ namespace fcg
             FlatScene& out_;
             std::vector<std::pair<uint32_t, uint32_t>> range_;
             std::vector<char> tri_only_;
+            size_t width_;
             uint32_t max_leaf_ = leaf_limit();
 
             static uint32_t leaf_limit()  // FCGPU_MAX_LEAF (development knob): 1 .. MAX_LEAF_PRIMS
@@ -617,7 +630,7 @@ namespace fcg
                 const BinNode& n = bin_.nodes[b];
                 push_bin(b + 1, kids, 0);
                 push_bin(n.a, kids, kids.size());
-                while(kids.size() < 4)
+                while(kids.size() < width_)
                 {
                     int best = -1;
                     float best_area = -1.0f;
@@ -688,6 +701,172 @@ namespace fcg
                 return static_cast<uint32_t>(kids.size() - 1) + deepest;
             }
 
+            // ---- 8-wide emission. Writes node `index` (already allocated) for `kids`, allocates its interior children as
+            // consecutive nodes, appends the records of its leaf children to tri_order8, recurses; returns the worst-case
+            // number of stack entries below it (the traversal pushes at most one group of pending siblings per level).
+            uint32_t emit8(uint32_t index, std::vector<WideChild> kids)
+            {
+                while(kids.size() > 8)
+                {
+                    std::vector<WideChild> tail(kids.end() - 8, kids.end());
+                    kids.erase(kids.end() - 8, kids.end());
+                    BoxF b;
+                    for(auto& k : tail) b.grow(k.box);
+                    pending_.push_back(std::move(tail));
+                    kids.push_back(WideChild{b, false, INVALID_U32, 0u, static_cast<uint32_t>(pending_.size() - 1), 0u});
+                }
+                BoxF box;
+                for(auto& k : kids) box.grow(k.box);
+                // slot assignment: child c prefers the slot whose corner its centre points at (bit a of the slot = the
+                // child lies on the + side of axis a), greedily by the largest projection onto the slot's diagonal
+                int slot_of[8], child_in[8];
+                for(int i = 0; i < 8; ++i) slot_of[i] = child_in[i] = -1;
+                float centre[3];
+                for(int a = 0; a < 3; ++a) centre[a] = 0.5f * (box.lo[a] + box.hi[a]);
+                for(size_t round = 0; round < kids.size(); ++round)
+                {
+                    float best = -std::numeric_limits<float>::max();
+                    int bc = -1, bs = -1;
+                    for(size_t c = 0; c < kids.size(); ++c)
+                    {
+                        if(slot_of[c] >= 0) continue;
+                        for(int sl = 0; sl < 8; ++sl)
+                        {
+                            if(child_in[sl] >= 0) continue;
+                            float score = 0.0f;
+                            for(int a = 0; a < 3; ++a)
+                                score += (0.5f * (kids[c].box.lo[a] + kids[c].box.hi[a]) - centre[a]) * ((sl >> a & 1) ? 1.0f : -1.0f);
+                            if(score > best)
+                            {
+                                best = score;
+                                bc = static_cast<int>(c);
+                                bs = sl;
+                            }
+                        }
+                    }
+                    slot_of[bc] = bs;
+                    child_in[bs] = bc;
+                }
+                Node8 node{};
+                node.ox = box.lo[0];
+                node.oy = box.lo[1];
+                node.oz = box.lo[2];
+                BoxF slot_box[8];
+                bool used[8];
+                for(int sl = 0; sl < 8; ++sl)
+                {
+                    used[sl] = child_in[sl] >= 0;
+                    if(used[sl]) slot_box[sl] = kids[static_cast<size_t>(child_in[sl])].box;
+                }
+                uint32_t lo_words[3][2], hi_words[3][2];
+                int exps[3];
+                quantise_slots(box, slot_box, used, 8, lo_words, hi_words, exps);
+                uint32_t imask = 0, valid = 0, two = 0, interior = 0;
+                for(int sl = 0; sl < 8; ++sl)
+                {
+                    if(!used[sl]) continue;
+                    valid |= 1u << sl;
+                    if(!kids[static_cast<size_t>(child_in[sl])].leaf)
+                    {
+                        imask |= 1u << sl;
+                        interior += 1;
+                    }
+                }
+                for(int a = 0; a < 3; ++a)
+                    for(int h = 0; h < 2; ++h)
+                    {
+                        node.qlo[a][h] = lo_words[a][h];
+                        node.qhi[a][h] = hi_words[a][h];
+                    }
+                node.exps = static_cast<uint32_t>(exps[0] + 127) | static_cast<uint32_t>(exps[1] + 127) << 8 | static_cast<uint32_t>(exps[2] + 127) << 16 | imask << 24;
+                const uint32_t child_base = static_cast<uint32_t>(out_.nodes8.size());
+                out_.nodes8.resize(out_.nodes8.size() + interior);
+                node.tri_base = static_cast<uint32_t>(tri_order8.size());
+                for(int sl = 0; sl < 8; ++sl)
+                {
+                    if(!used[sl] || (imask >> sl & 1u)) continue;
+                    const WideChild& k = kids[static_cast<size_t>(child_in[sl])];
+                    if(k.kind == KIND_TRI)
+                    {
+                        if(k.count > 2) error = "8-wide hierarchy: a leaf of more than two triangles (FCG_MAX_LEAF_PRIMS must be <= 2)";
+                        for(uint32_t q = 0; q < k.count; ++q) tri_order8.push_back(k.first + q);
+                        if(k.count == 2) two |= 1u << sl;
+                    }
+                    else
+                        tri_order8.push_back(XPRIM_PROXY_TAG | k.kind << 24 | k.first);
+                }
+                node.child_base = (child_base & 0x00FFFFFFu) | valid << 24;
+                node.two_mask = two;
+                out_.nodes8[index] = node;
+                uint32_t deepest = 0, rank = 0;
+                for(int sl = 0; sl < 8; ++sl)
+                {
+                    if(!used[sl] || !(imask >> sl & 1u)) continue;
+                    const WideChild& k = kids[static_cast<size_t>(child_in[sl])];
+                    std::vector<WideChild> sub;
+                    if(k.bin == INVALID_U32)
+                        sub = pending_[k.first];
+                    else
+                        gather(k.bin, sub);
+                    deepest = std::max(deepest, emit8(child_base + rank, std::move(sub)));
+                    rank += 1;
+                }
+                return interior ? 1u + deepest : 0u;
+            }
+
+        public:
+            static constexpr uint32_t XPRIM_PROXY_TAG = 0x80000000u;  // in tri_order8: kind << 24 | xprims index follow
+
+        private:
+            // quantised bounds of up to `n` child slots on the node's power-of-two grid (step 2^e per axis), conservative
+            // under the device's fp32 decode fma(q, step, origin); unused slots get the inverted interval [255, 0].
+            // words[axis][h]: byte c of word h = slot 4 h + c
+            static void quantise_slots(const BoxF& box, const BoxF* slot_box, const bool* used, int n, uint32_t (*lo_words)[2], uint32_t (*hi_words)[2], int* exps)
+            {
+                for(int a = 0; a < 3; ++a)
+                {
+                    float extent = box.hi[a] - box.lo[a];
+                    int e = -100;
+                    if(extent > 0.0f) e = static_cast<int>(std::ceil(std::log2(static_cast<double>(extent) / 255.0)));
+                    e = std::max(e, -120);
+                    for(;;)
+                    {
+                        float step = std::ldexp(1.0f, e);
+                        bool ok = true;
+                        uint32_t lw[2]{0, 0}, hw[2]{0, 0};
+                        for(int c = 0; c < n && ok; ++c)
+                        {
+                            uint32_t ql = 255, qh = 0;
+                            if(used[c])
+                            {
+                                double rl = (static_cast<double>(slot_box[c].lo[a]) - box.lo[a]) / step;
+                                double rh = (static_cast<double>(slot_box[c].hi[a]) - box.lo[a]) / step;
+                                long l = std::max(0l, static_cast<long>(std::floor(rl)));
+                                long h = static_cast<long>(std::ceil(rh));
+                                while(l > 0 && std::fmaf(static_cast<float>(l), step, box.lo[a]) > slot_box[c].lo[a]) --l;
+                                while(h <= 255 && std::fmaf(static_cast<float>(h), step, box.lo[a]) < slot_box[c].hi[a]) ++h;
+                                if(h > 255 || l > 255) ok = false;
+                                ql = static_cast<uint32_t>(l);
+                                qh = static_cast<uint32_t>(h);
+                            }
+                            lw[c >> 2] |= ql << (8 * (c & 3));
+                            hw[c >> 2] |= qh << (8 * (c & 3));
+                        }
+                        if(ok)
+                        {
+                            for(int h = 0; h < 2; ++h)
+                            {
+                                lo_words[a][h] = lw[h];
+                                hi_words[a][h] = hw[h];
+                            }
+                            exps[a] = e;
+                            break;
+                        }
+                        ++e;
+                    }
+                }
+            }
+
             std::vector<std::vector<WideChild>> pending_;
 
             static void quantise(const BoxF& box, const std::vector<WideChild>& kids, Node4& node)
@@ -742,6 +921,33 @@ namespace fcg
                 }
             }
         };
+
+#if FCG_TREELET
+        // Experiment (FCG_TREELET = n > 0, tools/build_variant.sh): the top of the hierarchy, the first n wide nodes in
+        // breadth-first order, is moved to indices 0 .. n-1, which the traversal kernels copy into LDS per block
+        // (fc_traverse.h); all other nodes keep their depth-first order behind them.
+        void treelet_first(std::vector<Node4>& nodes, uint32_t n)
+        {
+            std::vector<uint32_t> bfs{0u};
+            for(size_t head = 0; head < bfs.size() && bfs.size() < n; ++head)
+                for(uint32_t c : nodes[bfs[head]].child)
+                    if(c != INVALID_U32 && !child_is_leaf(c) && bfs.size() < n) bfs.push_back(c);
+            std::vector<uint32_t> new_index(nodes.size(), INVALID_U32);
+            for(size_t k = 0; k < bfs.size(); ++k) new_index[bfs[k]] = static_cast<uint32_t>(k);
+            uint32_t next = static_cast<uint32_t>(bfs.size());
+            for(size_t k = 0; k < nodes.size(); ++k)
+                if(new_index[k] == INVALID_U32) new_index[k] = next++;
+            std::vector<Node4> moved(nodes.size());
+            for(size_t k = 0; k < nodes.size(); ++k)
+            {
+                Node4 node = nodes[k];
+                for(uint32_t& c : node.child)
+                    if(c != INVALID_U32 && !child_is_leaf(c)) c = new_index[c];
+                moved[new_index[k]] = node;
+            }
+            nodes.swap(moved);
+        }
+#endif
 
         // ------------------------------------------------------------ typed conversion
         template<typename R> void put12(R* dst, const M4& m)
@@ -1097,7 +1303,8 @@ namespace fcg
         return n;
     }
 
-    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err, const HierarchyBuilder* device_builder, bool reference_split_rule)
+    int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err, const HierarchyBuilder* device_builder, bool reference_split_rule,
+                      int bvh_width)
     {
         out = FlatScene{};
         if(d.entity_count == 0 || d.surface_count == 0 || d.material_count == 0)
@@ -1529,8 +1736,59 @@ namespace fcg
             order_box[k] = refs[k].box;  // the build leaves refs in leaf order
             order_ki[k] = kind_index[bin.order[k]];
         }
-        WideBuilder wb{bin, order_box, order_ki, out};
+        if(bvh_width != 4 && bvh_width != 8)
+        {
+            err = "bvh_width must be 4 or 8";
+            return FCGPU_E_INVALID;
+        }
+        WideBuilder wb{bin, order_box, order_ki, out, bvh_width};
         wb.run();
+        if(!wb.error.empty())
+        {
+            err = wb.error;
+            return FCGPU_E_LIMIT;
+        }
+        if(bvh_width == 8)
+        {
+            // the triangle records move once more, into the order the 8-wide nodes reference them (each node's leaf
+            // children consecutive), with a proxy record per sphere / plane leaf; everything keyed by triangle index follows
+            std::vector<TriRec> moved(wb.tri_order8.size());
+            std::vector<uint32_t> new_slot(out.tris.size(), INVALID_U32);
+            for(size_t k = 0; k < wb.tri_order8.size(); ++k)
+            {
+                const uint32_t w = wb.tri_order8[k];
+                if(w & WideBuilder::XPRIM_PROXY_TAG)
+                {
+                    TriRec proxy{};
+                    proxy.prim = w & 0x00FFFFFFu;
+                    proxy.entity = (w >> 24) & 0x3u;
+                    proxy.attr = XPRIM_PROXY;
+                    moved[k] = proxy;
+                }
+                else
+                {
+                    moved[k] = out.tris[w];
+                    new_slot[w] = static_cast<uint32_t>(k);
+                }
+            }
+            for(size_t p = 0; p < kind_index.size(); ++p)
+            {
+                if((kind_index[p] >> 30) == KIND_TRI)
+                {
+                    kind_index[p] = (KIND_TRI << 30) | new_slot[kind_index[p] & 0x3FFFFFFFu];
+                    out.prim_info[p].kind_index = kind_index[p];
+                }
+            }
+            out.tris.swap(moved);
+            if(out.tris.empty()) out.tris.push_back(TriRec{});
+            make_tri_shade(out.tris, out.tri_attrs, out.f32.tri_shade);
+            make_tri_shade(out.tris, out.tri_attrs, out.f64.tri_shade);
+            out.nodes.assign(1, Node4{});  // unused: the 4-wide array stays a valid (empty-rooted) allocation
+            for(uint32_t& c : out.nodes[0].child) c = INVALID_U32;
+        }
+#if FCG_TREELET
+        treelet_first(out.nodes, FCG_TREELET);
+#endif
         if(out.max_stack > static_cast<uint32_t>(STACK_CAP + STACK_SPILL_MAX))
         {
             err = "BVH needs a deeper traversal stack than STACK_CAP + STACK_SPILL_MAX";

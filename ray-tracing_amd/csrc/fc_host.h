@@ -42,6 +42,7 @@ namespace fcg
     struct FlatScene
     {
         std::vector<Node4> nodes;
+        std::vector<Node8> nodes8;  // instead of `nodes` when the 8-wide hierarchy was asked for (bvh_width 8)
         std::vector<TriRec> tris;
         std::vector<TriAttr> tri_attrs;
         std::vector<PrimInfo> prim_info;
@@ -75,8 +76,9 @@ namespace fcg
     // Returns FCGPU_OK or a negative error code with a message in `err`. `device_builder`: build the binary hierarchy
     // there instead of with the host's SAH builder (scenes of fewer than 2 primitives always use the host).
     // `reference_split_rule`: the host builder searches splits exactly as the reference does (FCGPU_BVH_HOST_REFERENCE).
+    // `bvh_width`: 4 (Node4, the default) or 8 (Node8).
     int flatten_scene(const fcgpu_scene_desc& d, FlatScene& out, std::string& err, const HierarchyBuilder* device_builder = nullptr,
-                      bool reference_split_rule = false);
+                      bool reference_split_rule = false, int bvh_width = 4);
 
     // Lobes of one constant material (material::evaluate + the bsdf constructor) as an upload precomputes them: double
     // arithmetic, converted per precision. Returns the lobe count or a negative error code.

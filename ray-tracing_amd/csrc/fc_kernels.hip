@@ -261,6 +261,22 @@ namespace fcg
         if(blockIdx.x == 0 && threadIdx.x == 0) Q.counters->ray[B.parity][0] = n;
     }
 
+    // Experiment FCG_TREELET: every block copies the top of the hierarchy into its LDS (fc_traverse.h fetches from there)
+    template<typename R> FC_D void treelet_fill(const SceneDev<R>& S, unsigned char* lds)
+    {
+#if FCG_TREELET
+        const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        const uint32_t have = S.node_count < static_cast<uint32_t>(FCG_TREELET) ? S.node_count : static_cast<uint32_t>(FCG_TREELET);
+        for(uint32_t i = threadIdx.x; i < 4u * have; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+#endif
+    }
+
+    // WIDE8 instantiations traverse the 8-wide hierarchy (Node8, fcgpu_options.bvh_width = 8) instead of the 4-wide one
+    template<typename R, bool WIDE8> struct TravSel { typedef Trav<R> type; };
+    template<typename R> struct TravSel<R, true> { typedef Trav8<R> type; };
+
     // ------------------------------------------------------------------ extend
     // Persistent waves with dynamic ray fetch: a lane whose ray is finished does not idle until the
     // slowest ray of its wave ends; once FINISH_MIN lanes of the wave have finished (or nothing is
@@ -324,17 +340,24 @@ namespace fcg
 
     // TEX: the scene has materials with image textures (per-hit lobe construction compiled in: +5 % shade time, so
     // scenes without them run the instantiations without it)
-    template<typename R, bool PROF, bool SPILL, bool TEX>
-    __global__ __launch_bounds__(BLOCK) void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    // FCG_EXTEND_WAVES (experiment, tools/build_variant.sh): makes the compiler fit k_extend into the registers of that many waves per SIMD
+#ifdef FCG_EXTEND_WAVES
+#define FCG_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(FCG_EXTEND_WAVES, FCG_EXTEND_WAVES)))
+#else
+#define FCG_EXTEND_ATTR
+#endif
+    template<typename R, bool PROF, bool SPILL, bool TEX, bool WIDE8 = false>
+    __global__ __launch_bounds__(BLOCK) FCG_EXTEND_ATTR void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         // PROF: descent, leaf cycles, trips, leaf phases, finish cycles, finish phases, leaf lanes, finish lanes, cycles of the finish phase's
         // three parts (hit record, work_take, ray load + set-up), per-lane node steps that found nothing, of those emptied by t_max,
         // lanes waiting with a leaf / with a finished ray summed over the descent trips
         unsigned long long ph[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
-        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
+        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[FCG_TREELET ? FCG_TREELET * 64 : WAVES * NODEBUF_WAVE];
         uint32_t* stack = stack_lds + threadIdx.x;
-        unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
+        unsigned char* nodebuf = FCG_TREELET ? nodebuf_lds : nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
+        treelet_fill(S, nodebuf_lds);
         const uint32_t n = Q.counters->ray[B.parity][0];
         uint32_t n_cast = 0, n_moverflow = 0, n_mdeep = 0, n_nodes = 0, n_prims = 0;
         StackStats n_overflow;
@@ -344,9 +367,8 @@ namespace fcg
         const uint32_t dim_lobe = 2u + (B.integrator == FCGPU_INTEGRATOR_MIS ? 6u : 3u) * static_cast<uint32_t>(B.h - 1);
 
         WorkCursor W = work_begin(n);
-        Trav<R> T;
-        T.cur = INVALID_U32;
-        T.sp = 0;
+        typename TravSel<R, WIDE8>::type T;
+        trav_idle(T);
         uint32_t slot = INVALID_U32;  // ray-queue index this lane is working on
         uint32_t path = 0, ms = 0;
         vec3<R> dir{};
@@ -546,7 +568,10 @@ namespace fcg
                     ph[10] += c3 - c2;
                 }
             }
-            trav_round<R, false, BLOCK, SPILL, PROF>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims, ph);
+            if constexpr(WIDE8)
+                trav_round8<R, false, BLOCK>(S, T, stack, n_overflow, B.descend_min, n_nodes, n_prims);
+            else
+                trav_round<R, false, BLOCK, SPILL, PROF>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims, ph);
             n_rounds += 1;
         }
         if(PROF)
@@ -1089,20 +1114,20 @@ namespace fcg
     }
 
     // ------------------------------------------------------------------ shadow
-    template<typename R, bool SPILL>
+    template<typename R, bool SPILL, bool WIDE8 = false>
     __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
-        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
+        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[FCG_TREELET ? FCG_TREELET * 64 : WAVES * NODEBUF_WAVE];
         uint32_t* stack = stack_lds + threadIdx.x;
-        unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
+        unsigned char* nodebuf = FCG_TREELET ? nodebuf_lds : nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
+        treelet_fill(S, nodebuf_lds);
         const uint32_t n = Q.counters->shadow[0];
         uint32_t n_cast = 0, n_occ = 0, n_nodes = 0, n_prims = 0;
         StackStats n_overflow;
         WorkCursor W = work_begin(n);
-        Trav<R> T;
-        T.cur = INVALID_U32;
-        T.sp = 0;
+        typename TravSel<R, WIDE8>::type T;
+        trav_idle(T);
         uint32_t slot = INVALID_U32, path = 0;
         for(;;)
         {
@@ -1140,7 +1165,10 @@ namespace fcg
                 }
                 if(__ballot(slot != INVALID_U32) == 0ull) break;
             }
-            trav_round<R, true, BLOCK, SPILL>(S, T, stack, nodebuf, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
+            if constexpr(WIDE8)
+                trav_round8<R, true, BLOCK>(S, T, stack, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
+            else
+                trav_round<R, true, BLOCK, SPILL>(S, T, stack, nodebuf, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
         }
         wave_stat_add(Q.stats, ST_SHADOW, n_cast);
         wave_stat_add(Q.stats, ST_OCCLUDED, n_occ);
@@ -1203,13 +1231,31 @@ namespace fcg
 #endif
 
     // ------------------------------------------------------------------ parity hooks
-    template<typename R, bool SPILL>
+    // whole-wave wrapper over the 8-wide rounds (like fc_traverse.h: traverse)
+    template<typename R, bool ANY>
+    FC_D bool traverse8(const SceneDev<R>& S, bool active, vec3<R> o, vec3<R> d, R t_max, uint32_t* stack, R& t_out, uint32_t& pk_out, R& b0_out, R& b1_out,
+                        StackStats& overflow)
+    {
+        Trav8<R> T;
+        trav_begin(T, o, d, t_max);
+        if(!active) trav_idle(T);
+        uint32_t nn = 0, np = 0;
+        while(__ballot(!trav_done(T)) != 0ull) trav_round8<R, ANY, BLOCK>(S, T, stack, overflow, 12, nn, np);
+        t_out = T.t_max;
+        pk_out = T.pk;
+        b0_out = T.b0;
+        b1_out = T.b1;
+        return T.pk != INVALID_U32;
+    }
+
+    template<typename R, bool SPILL, bool WIDE8 = false>
     __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev<R> S, uint64_t n, const fcgpu_ray* rays, fcgpu_hit* hits,
                                                      uint8_t* occluded, unsigned long long* stats)
     {
         __shared__ uint32_t stack[STACK_CAP * BLOCK];
-        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[WAVES * NODEBUF_WAVE];
-        unsigned char* nodebuf = nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
+        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[FCG_TREELET ? FCG_TREELET * 64 : WAVES * NODEBUF_WAVE];
+        unsigned char* nodebuf = FCG_TREELET ? nodebuf_lds : nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
+        treelet_fill(S, nodebuf_lds);
         StackStats n_overflow;
         // block-uniform trip count: every lane of a wave takes part in the cooperative node fetches
         for(uint64_t base = static_cast<uint64_t>(blockIdx.x) * BLOCK; base < n; base += static_cast<uint64_t>(gridDim.x) * BLOCK)
@@ -1225,7 +1271,11 @@ namespace fcg
             if(hits != nullptr)
             {
                 fcgpu_hit h{};
-                const bool hit = traverse<R, false, BLOCK, SPILL>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
+                bool hit;
+                if constexpr(WIDE8)
+                    hit = traverse8<R, false>(S, active, rc.o, rc.d, R(r.t_max), stack + threadIdx.x, t, pk, b0, b1, n_overflow);
+                else
+                    hit = traverse<R, false, BLOCK, SPILL>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
                 if(hit)
                 {
                     vec3<R> p, nrm;
@@ -1245,7 +1295,11 @@ namespace fcg
             }
             else
             {
-                const bool hit = traverse<R, true, BLOCK, SPILL>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
+                bool hit;
+                if constexpr(WIDE8)
+                    hit = traverse8<R, true>(S, active, rc.o, rc.d, R(r.t_max), stack + threadIdx.x, t, pk, b0, b1, n_overflow);
+                else
+                    hit = traverse<R, true, BLOCK, SPILL>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
                 if(active) occluded[i] = hit ? 1 : 0;
             }
         }
@@ -1399,7 +1453,14 @@ namespace fcg
         // SPILL variants only for scenes whose BVH needs more stack than the LDS holds (S.stack_spill set at upload),
         // TEX variants only for scenes with textured materials
         const dim3 g(L.grid), b(BLOCK);
-        if(S.textured_materials)
+        if(S.nodes8)
+        {
+            if(S.textured_materials)
+                hipLaunchKernelGGL((k_extend<R, false, false, true, true>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
+            else
+                hipLaunchKernelGGL((k_extend<R, false, false, false, true>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
+        }
+        else if(S.textured_materials)
         {
             if(S.stack_spill)
                 hipLaunchKernelGGL((k_extend<R, false, true, true>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
@@ -1446,7 +1507,9 @@ namespace fcg
     }
     template<typename R> void launch_shadow(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
-        if(S.stack_spill)
+        if(S.nodes8)
+            hipLaunchKernelGGL((k_shadow<R, false, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
+        else if(S.stack_spill)
             hipLaunchKernelGGL((k_shadow<R, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
         else
             hipLaunchKernelGGL((k_shadow<R, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
@@ -1464,7 +1527,9 @@ namespace fcg
     template<typename R> void launch_trace(const LaunchCfg& L, const SceneDev<R>& S, uint64_t n, const fcgpu_ray* rays,
                                            fcgpu_hit* hits, uint8_t* occluded, unsigned long long* stats)
     {
-        if(S.stack_spill)
+        if(S.nodes8)
+            hipLaunchKernelGGL((k_trace<R, false, true>), dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);
+        else if(S.stack_spill)
             hipLaunchKernelGGL((k_trace<R, true>), dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);
         else
             hipLaunchKernelGGL((k_trace<R, false>), dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);

@@ -403,6 +403,20 @@ namespace fcg
 #else
                 const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
 #endif
+#if FCG_TREELET
+                // top of the tree from the block's LDS copy (`nodebuf` is that copy in this build), the rest from L1 / L2
+                uint4 nq[4];
+                if(cur < static_cast<uint32_t>(FCG_TREELET))
+                {
+                    const uint4* lp = reinterpret_cast<const uint4*>(nodebuf) + 4u * cur;
+                    nq[0] = lp[0], nq[1] = lp[1], nq[2] = lp[2], nq[3] = lp[3];
+                }
+                else
+                {
+                    nq[0] = np[0], nq[1] = np[1], nq[2] = np[2], nq[3] = np[3];
+                }
+                np = nq;
+#endif
                 uint32_t next = node_step<R, ANY, STRIDE, SPILL>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, static_cast<int>(S.stack_spill_cap), sp, overflow, lost_push);
                 if(PROF) n_nodes += 1;  // per lane (the timeline wants the lane maximum); otherwise per wave, below
                 if(PROF && next == INVALID_U32)
@@ -480,6 +494,232 @@ namespace fcg
         T.cur = cur;
         T.sp = sp;
         if(PROF) ph[1] += clock64() - c1;
+    }
+
+    // ------------------------------------------------------------------ 8-wide hierarchy (Node8, fc_types.h)
+    // Per-lane state. `word` != 0: the lane holds the hit LEAF children of the node it stepped last (`cur` = that node's
+    // tri_base; word = hits in visiting order (8) | leaf slots (8) | two-record slots (8) | bit 31) and waits for the
+    // wave's leaf phase. word == 0: `cur` is the node to step next, or INVALID_U32 = finished. The groups of hit
+    // INTERIOR children that still wait live on the LDS stack, two words each: {child_base, hits in visiting order (8) |
+    // imask (8)}; visiting order = slot XOR the ray's octant, lowest first.
+    template<typename R>
+    struct Trav8
+    {
+        RayCtx<R> rc;
+        R t_max;
+        R b0, b1;
+        uint32_t pk;
+        uint32_t cur, word;
+        uint32_t oct;  // bit a: the ray travels towards -a
+        int sp;        // group entries on the stack
+    };
+
+    template<typename R> FC_D void trav_begin(Trav8<R>& T, vec3<R> o, vec3<R> d, R t_max)
+    {
+        T.rc = make_ray(o, d);
+        T.t_max = t_max;
+        T.b0 = R(0);
+        T.b1 = R(0);
+        T.pk = INVALID_U32;
+        T.cur = 0;
+        T.word = 0;
+        T.oct = (T.rc.negx ? 1u : 0u) | (T.rc.negy ? 2u : 0u) | (T.rc.negz ? 4u : 0u);
+        T.sp = 0;
+    }
+    template<typename R> FC_D bool trav_done(const Trav8<R>& T) { return T.cur == INVALID_U32; }
+    template<typename R> FC_D void trav_idle(Trav8<R>& T)
+    {
+        T.cur = INVALID_U32;
+        T.word = 0;
+        T.sp = 0;
+    }
+    template<typename R> FC_D void trav_idle(Trav<R>& T)
+    {
+        T.cur = INVALID_U32;
+        T.sp = 0;
+    }
+
+    // next node of the topmost group, or INVALID_U32 when the stack is empty
+    template<int STRIDE> FC_D uint32_t pop8(uint32_t* stack, int& sp, uint32_t oct)
+    {
+        if(sp == 0) return INVALID_U32;
+        const uint32_t base = stack[(2 * (sp - 1)) * STRIDE];
+        uint32_t w = stack[(2 * (sp - 1) + 1) * STRIDE];
+        const uint32_t k = static_cast<uint32_t>(__builtin_ctz(w)), slot = k ^ oct;  // (w & 0xFF) != 0 for every entry on the stack
+        const uint32_t next = base + static_cast<uint32_t>(__builtin_popcount((w >> 8) & ((1u << slot) - 1u)));
+        w &= w - 1u;
+        if(w & 0xFFu)
+            stack[(2 * (sp - 1) + 1) * STRIDE] = w;
+        else
+            sp -= 1;
+        return next;
+    }
+
+    // entry / exit distances of two children per call: byte c and c + 1 of the near / far plane words
+    template<typename R> struct planes8
+    {
+        static FC_D void run(uint32_t q, int c, R a, R b, R& p0, R& p1)
+        {
+            p0 = byte_to_real<R>(q, c) * a + b;
+            p1 = byte_to_real<R>(q, c + 1) * a + b;
+        }
+    };
+    template<> struct planes8<float>
+    {
+        static FC_D void run(uint32_t q, int c, float a, float b, float& p0, float& p1)
+        {
+            const f32x2 v = slab4<float>::planes(q, c, a, b);
+            p0 = v.x;
+            p1 = v.y;
+        }
+    };
+
+    // One step on an 8-wide node: which children the ray hits, as masks in visiting order; pushes the interior group,
+    // leaves the leaf group in (cur, word) or pops the next node. Returns false when a push found no room (counted by the caller).
+    template<typename R, int STRIDE>
+    FC_D bool node_step8(const RayCtx<R>& rc, uint32_t oct, R t_max, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, const uint4 n4,
+                         uint32_t* stack, int& sp, uint32_t& cur, uint32_t& word)
+    {
+        const R ox = R(__builtin_bit_cast(float, n0.x)), oy = R(__builtin_bit_cast(float, n0.y)), oz = R(__builtin_bit_cast(float, n0.z));
+        const uint32_t ex = n0.w;
+        const R ax = R(__builtin_bit_cast(float, (ex & 0xFFu) << 23)) * rc.inv_d.x;
+        const R ay = R(__builtin_bit_cast(float, (ex & 0xFF00u) << 15)) * rc.inv_d.y;
+        const R az = R(__builtin_bit_cast(float, (ex & 0xFF0000u) << 7)) * rc.inv_d.z;
+        const R bx = (ox - rc.o.x) * rc.inv_d.x, by = (oy - rc.o.y) * rc.inv_d.y, bz = (oz - rc.o.z) * rc.inv_d.z;
+        // n2 = qlo x (2), qlo y (2); n3 = qlo z (2), qhi x (2); n4 = qhi y (2), qhi z (2)
+        const uint32_t nx[2]{rc.negx ? n3.z : n2.x, rc.negx ? n3.w : n2.y}, fx[2]{rc.negx ? n2.x : n3.z, rc.negx ? n2.y : n3.w};
+        const uint32_t ny[2]{rc.negy ? n4.x : n2.z, rc.negy ? n4.y : n2.w}, fy[2]{rc.negy ? n2.z : n4.x, rc.negy ? n2.w : n4.y};
+        const uint32_t nz[2]{rc.negz ? n4.z : n3.x, rc.negz ? n4.w : n3.y}, fz[2]{rc.negz ? n3.x : n4.z, rc.negz ? n3.y : n4.w};
+        uint32_t hits = 0;  // slot order
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
+        {
+#pragma unroll
+            for(int c = 0; c < 4; c += 2)
+            {
+                R tnx0, tnx1, tny0, tny1, tnz0, tnz1, tfx0, tfx1, tfy0, tfy1, tfz0, tfz1;
+                planes8<R>::run(nx[h], c, ax, bx, tnx0, tnx1);
+                planes8<R>::run(ny[h], c, ay, by, tny0, tny1);
+                planes8<R>::run(nz[h], c, az, bz, tnz0, tnz1);
+                planes8<R>::run(fx[h], c, ax, bx, tfx0, tfx1);
+                planes8<R>::run(fy[h], c, ay, by, tfy0, tfy1);
+                planes8<R>::run(fz[h], c, az, bz, tfz0, tfz1);
+                const R tn0 = r_max(r_max(tnx0, tny0), r_max(tnz0, R(0))), tf0 = r_min(r_min(tfx0, tfy0), r_min(tfz0, t_max));
+                const R tn1 = r_max(r_max(tnx1, tny1), r_max(tnz1, R(0))), tf1 = r_min(r_min(tfx1, tfy1), r_min(tfz1, t_max));
+                hits |= (tn0 <= tf0 * R(1.0000005) ? 1u : 0u) << (4 * h + c);
+                hits |= (tn1 <= tf1 * R(1.0000005) ? 1u : 0u) << (4 * h + c + 1);
+            }
+        }
+        const uint32_t valid = n1.x >> 24, imask = ex >> 24;
+        hits &= valid;
+        // interior hits in byte 0, leaf hits in byte 1: both into visiting order (bit k = slot k XOR oct)
+        uint32_t x = (hits & imask) | (hits & ~imask) << 8;
+        const uint32_t x1 = ((x & 0x5555u) << 1) | ((x >> 1) & 0x5555u);
+        x = (oct & 1u) ? x1 : x;
+        const uint32_t x2 = ((x & 0x3333u) << 2) | ((x >> 2) & 0x3333u);
+        x = (oct & 2u) ? x2 : x;
+        const uint32_t x4 = ((x & 0x0F0Fu) << 4) | ((x >> 4) & 0x0F0Fu);
+        x = (oct & 4u) ? x4 : x;
+        const uint32_t int_key = x & 0xFFu, leaf_key = x >> 8;
+        bool room = true;
+        if(int_key)
+        {
+            room = sp < STACK8_CAP;
+            if(room)
+            {
+                stack[(2 * sp) * STRIDE] = n1.x & 0x00FFFFFFu;
+                stack[(2 * sp + 1) * STRIDE] = int_key | imask << 8;
+                sp += 1;
+            }
+        }
+        if(leaf_key)
+        {
+            cur = n1.y;
+            word = leaf_key | (valid & ~imask) << 8 | (n1.z & 0xFFu) << 16 | 0x80000000u;
+        }
+        else
+            cur = pop8<STRIDE>(stack, sp, oct);
+        return room;
+    }
+
+    // One round for the whole wave, like trav_round: lanes holding a node step until enough of them hold leaves, then the
+    // lanes holding leaves test ONE hit leaf child (at most two records) each.
+    template<typename R, bool ANY, int STRIDE>
+    FC_D void trav_round8(const SceneDev<R>& S, Trav8<R>& T, uint32_t* stack, StackStats& overflow, int descend_min, uint32_t& n_nodes, uint32_t& n_prims)
+    {
+        uint32_t cur = T.cur, word = T.word;
+        int sp = T.sp;
+        bool leaf_waiting = __ballot(word != 0u) != 0ull;
+        for(;;)
+        {
+            const bool descending = word == 0u && cur != INVALID_U32;
+            const uint64_t dm = __ballot(descending);
+            if(dm == 0ull || (leaf_waiting && __popcll(dm) < descend_min)) break;
+            bool lost_push = false;
+            if(descending)
+            {
+                const uint4* np = reinterpret_cast<const uint4*>(S.nodes8 + cur);
+                lost_push = !node_step8<R, STRIDE>(T.rc, T.oct, T.t_max, np[0], np[1], np[2], np[3], np[4], stack, sp, cur, word);
+            }
+            n_nodes += __popcll(dm);
+            overflow.lost += __popcll(__ballot(lost_push));
+            leaf_waiting = leaf_waiting || __ballot(word != 0u) != 0ull;
+        }
+        if(word != 0u)
+        {
+            const uint32_t k = static_cast<uint32_t>(__builtin_ctz(word)), slot = k ^ T.oct, below = (1u << slot) - 1u;
+            const uint32_t leaf_slots = (word >> 8) & 0xFFu, two = (word >> 16) & 0xFFu;
+            const uint32_t first = cur + static_cast<uint32_t>(__builtin_popcount(leaf_slots & below)) + static_cast<uint32_t>(__builtin_popcount(two & below));
+            const uint32_t count = 1u + ((two >> slot) & 1u);
+            n_prims += count;
+            TriRec tr[2];
+            tr[0] = S.tris[first];
+            if(count > 1u) tr[1] = S.tris[first + 1u];
+            bool stop = false;
+#pragma unroll
+            for(uint32_t j = 0; j < 2u; ++j)
+            {
+                if(j < count && !stop)
+                {
+                    R t, b0 = R(0), b1 = R(0);
+                    bool hit;
+                    uint32_t pk;
+                    if(tr[j].attr == XPRIM_PROXY)
+                    {
+                        const uint32_t kind = tr[j].entity, idx = tr[j].prim;
+                        hit = kind == KIND_SPHERE ? sphere_intersect(S.xprims[idx], T.rc, T.t_max, t) : plane_intersect(S.xprims[idx], T.rc, T.t_max, t);
+                        pk = (kind << 30) | idx;
+                    }
+                    else
+                    {
+                        hit = tri_intersect(tr[j], T.rc, T.t_max, t, b0, b1);
+                        pk = (KIND_TRI << 30) | (first + j);
+                    }
+                    if(hit)
+                    {
+                        T.t_max = t;
+                        T.pk = pk;
+                        T.b0 = b0;
+                        T.b1 = b1;
+                        if(ANY) stop = true;
+                    }
+                }
+            }
+            word &= word - 1u;  // this leaf is done
+            if(stop)
+            {
+                cur = INVALID_U32;
+                word = 0u;
+            }
+            else if((word & 0xFFu) == 0u)
+            {
+                word = 0u;
+                cur = pop8<STRIDE>(stack, sp, T.oct);
+            }
+        }
+        T.cur = cur;
+        T.word = word;
+        T.sp = sp;
     }
 
     // Whole-wave convenience wrapper (parity hooks): runs rounds until every ray of the wave is finished.

@@ -19,6 +19,12 @@ namespace fcg
 
     constexpr uint32_t INVALID_U32 = 0xFFFFFFFFu;
 
+    // Experiment: the first FCG_TREELET wide nodes (breadth-first top of the hierarchy, fc_host.cpp: treelet_first) are
+    // copied into LDS by every block of a traversal kernel and fetched from there (0 = off, the default)
+#ifndef FCG_TREELET
+#define FCG_TREELET 0
+#endif
+
     // ---- BVH
     constexpr uint32_t NODE_LEAF_BIT = 0x80000000u;
 #ifndef FCG_MAX_LEAF_PRIMS
@@ -45,6 +51,28 @@ namespace fcg
         uint32_t child[4];      // interior: node index; leaf: NODE_LEAF_BIT | kind<<29 | (count-1)<<26 | first; empty: INVALID_U32
     };
     static_assert(sizeof(Node4) == 64, "Node4 must be one 64-byte line");
+
+    // The 8-wide node (fcgpu_options.bvh_width = 8; Ylitie, Karras, Laine 2017 in spirit): 80 bytes = five 16-byte pieces.
+    // Children sit in SLOTS chosen by the builder from where they lie in the node (slot bit 0 / 1 / 2 = the +x / +y / +z
+    // side), so that a ray visits the hit children in order of (slot XOR the ray's octant) without sorting distances;
+    // interior children are consecutive nodes (in slot order) and the triangles of the leaf children consecutive records
+    // (in slot order), so one index each and a few mask bits stand for all eight children. A sphere or plane is a leaf
+    // of one PROXY record in the triangle array (TriRec::attr = XPRIM_PROXY, ::prim = index into xprims, ::entity = kind).
+    struct alignas(16) Node8
+    {
+        float ox, oy, oz;     // grid origin (= node box minimum)
+        uint32_t exps;        // bytes 0..2: biased exponents of the grid steps along x, y, z (step = 2^(e - 127)); byte 3: imask, bit s = slot s is an interior node
+        uint32_t child_base;  // bits 0..23: first interior child; bits 24..31: valid mask, bit s = slot s holds a child
+        uint32_t tri_base;    // first record of the leaf children's triangles
+        uint32_t two_mask;    // bits 0..7: leaf slot s holds two records (else one); rest 0
+        uint32_t pad;
+        uint32_t qlo[3][2];   // [axis][half]: byte c of half h = quantised lower bound of slot 4 h + c
+        uint32_t qhi[3][2];
+    };
+    static_assert(sizeof(Node8) == 80, "Node8 is five 16-byte pieces");
+    constexpr uint32_t XPRIM_PROXY = 0xFFFFFFFEu;
+    constexpr uint32_t NODE8_MAX_NODES = 1u << 24;
+    constexpr int STACK8_CAP = STACK_CAP / 2;  // group entries of the 8-wide traversal: two words each in the same LDS array
 
     FC_HD bool child_is_leaf(uint32_t c) { return (c & NODE_LEAF_BIT) != 0; }
     // leaf word: first = index into tris (KIND_TRI, `count` consecutive records) or xprims (count 1)
@@ -227,6 +255,7 @@ namespace fcg
     struct SceneDev
     {
         const Node4* nodes;
+        const Node8* nodes8;  // non-null: the scene was flattened 8-wide (bvh_width 8) and the kernels run their WIDE8 instantiations
         const TriRec* tris;
         const TriAttr* tri_attrs;
         const XPrim<R>* xprims;
@@ -242,6 +271,7 @@ namespace fcg
         const TriShade<R>* tri_shade;  // by triangle index
         uint32_t* stack_spill;     // [depth - STACK_CAP][grid lanes] or nullptr when the BVH fits the LDS stack
         uint32_t stack_spill_stride;
+        uint32_t node_count;       // wide nodes
         uint32_t stack_spill_cap;  // entries per lane column of stack_spill: pushes beyond STACK_CAP + this are counted as lost
         uint32_t textured_materials;  // 1 = some material has image textures (selects the TEX kernel instantiations)
         CameraRec<R> camera;

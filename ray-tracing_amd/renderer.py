@@ -78,12 +78,13 @@ def load_library():
     return lib
 
 
-def check_scene(scene, bvh_builder="host"):
+def check_scene(scene, bvh_builder="host", bvh_width=4):
     """Validates `scene` and builds its hierarchy on the host, no device needed (fcgpu_check_scene): SceneStats."""
     lib = load_library()
     desc = scene.desc()
     st = A.SceneStats()
-    rc = lib.fcgpu_check_scene(C.byref(desc), {"host": A.BVH_HOST_SAH, "reference": A.BVH_HOST_REFERENCE}[bvh_builder], C.byref(st))
+    builder = {"host": A.BVH_HOST_SAH, "reference": A.BVH_HOST_REFERENCE}[bvh_builder] | (A.BVH_WIDE8 if bvh_width == 8 else 0)
+    rc = lib.fcgpu_check_scene(C.byref(desc), builder, C.byref(st))
     if rc != 0:
         raise FcgpuError(rc, (lib.fcgpu_last_error(None) or b"").decode())
     return st
@@ -134,13 +135,15 @@ class GpuContext:
         self.close()
 
     def set_options(self, precision="f32", epsilon=0.0, max_paths_in_flight=0, sort_materials=True, bvh_builder="host",
-                    origin_offset="default"):
+                    origin_offset="default", bvh_width=None):
         """bvh_builder: "host" = SAH build on the host (three-axis split search), "device" = linear BVH built on the GPU,
         "reference" = host SAH build with the reference's own split search (its tree)."""
         o = A.Options(precision=A.PRECISION_F64 if precision == "f64" else A.PRECISION_F32,
                       sort_materials=int(sort_materials), epsilon=epsilon, max_paths_in_flight=max_paths_in_flight,
                       bvh_builder={"host": A.BVH_HOST_SAH, "device": A.BVH_DEVICE_LBVH, "reference": A.BVH_HOST_REFERENCE}[bvh_builder],
-                      origin_offset={"default": A.OFFSET_DEFAULT, "normal": A.OFFSET_NORMAL, "along_ray": A.OFFSET_ALONG_RAY}[origin_offset])
+                      origin_offset={"default": A.OFFSET_DEFAULT, "normal": A.OFFSET_NORMAL, "along_ray": A.OFFSET_ALONG_RAY}[origin_offset],
+                      # development knob: FCGPU_BVH_WIDTH=8 runs everything that does not say otherwise on the 8-wide hierarchy
+                      bvh_width=int(os.environ.get("FCGPU_BVH_WIDTH", "0")) if bvh_width is None else bvh_width)
         self._check(self.lib.fcgpu_set_options(self.h, C.byref(o)))
 
     def upload_scene(self, scene):

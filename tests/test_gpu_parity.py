@@ -212,6 +212,54 @@ def test_other_builders_radiance_f64_matches_reference(name, builder):
     assert c.closest_rays == int(z["mis_rays"][0])
 
 
+# ------------------------------------------------------------------ the 8-wide hierarchy (fcgpu_options.bvh_width = 8)
+@pytest.mark.parametrize("name", RAY_FIXTURES)
+def test_eight_wide_hierarchy_returns_the_reference_hits(name):
+    """Node8 (80-byte node, octant-ordered child slots, sphere / plane leaves as proxy records): same closest hits, distances
+    and occlusion answers as the reference on the golden ray sets, in both precisions' WIDE8 kernels."""
+    z, scene = load_rays(name)
+    with make_ctx(scene, "f64", bvh_width=8) as ctx:
+        hits = ctx.trace_closest(z["rays"])
+        anyh = ctx.trace_any(z["rays"])
+        assert ctx.counters().stack_overflows == 0
+    mismatch = hits["prim"] != z["bvh_prim"]
+    assert mismatch.mean() <= 1e-4, f"prim id mismatches {mismatch.sum()} / {len(mismatch)}"
+    ok = (~mismatch) & (z["bvh_prim"] != 0xFFFFFFFF)
+    assert np.allclose(hits["t"][ok], z["bvh_t"][ok], rtol=1e-9, atol=1e-9)
+    assert (anyh != z["any_hit"]).mean() <= 1e-4
+    with make_ctx(scene, "f32", bvh_width=8) as ctx:
+        h32 = ctx.trace_closest(z["rays32"])
+        assert ctx.counters().stack_overflows == 0
+    mismatch, near_tie, ends = classify_id_mismatches(h32, z["rays32_prim"], z["rays32_t"], z["rays32"]["t_max"])
+    assert not (mismatch & ~near_tie & ~ends).any() and near_tie.mean() <= 1e-3
+
+
+@pytest.mark.parametrize("name", ["room_t4", "zoo", "mask", "nested_rough", "glass", "textured", "nested_deep9"])
+def test_eight_wide_hierarchy_radiance_f64_matches_reference(name):
+    z, scene = load_film(name)
+    with make_ctx(scene, "f64", bvh_width=8) as ctx:
+        ctx.set_sampler(int(z["seed"]), stratified=film_stratified(z))
+        ctx.render_pass(0, int(z["spp"]), A.INTEGRATOR_MIS, int(z["max_path_length"]), True)
+        rgb, n = ctx.read_film()
+        c = ctx.counters()
+    assert n == int(z["mis_count"]) and c.stack_overflows == 0 and c.medium_overflows == 0
+    assert pixel_rel_err(rgb, z["mis_rgb_sum"]).max() <= 1e-9
+    assert c.closest_rays == int(z["mis_rays"][0])
+
+
+def test_eight_wide_hierarchy_refuses_what_its_stack_cannot_hold():
+    from common import ribbon_scene
+
+    with R.GpuContext(0) as ctx:
+        ctx.set_options(precision="f32", bvh_width=8)
+        with pytest.raises(R.FcgpuError) as e:
+            ctx.upload_scene(ribbon_scene(420))
+        assert e.value.code == A.E_LIMIT and "bvh_width 4" in str(e.value)
+        with pytest.raises(R.FcgpuError) as e:
+            ctx.set_options(precision="f32", bvh_width=6)
+        assert e.value.code == A.E_INVALID
+
+
 def test_all_builders_agree_on_a_large_mesh():
     """196 608 wall triangles in fp32: the three hierarchies cast the same rays and render the same image up to the few
     paths whose exact-tie hits (shared triangle edges) resolve to the neighbouring triangle; the default build takes

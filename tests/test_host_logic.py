@@ -120,6 +120,21 @@ def test_every_scene_builder_flattens_on_the_host():
         assert st.primitives == sc.primitive_total(), name
 
 
+def test_every_scene_flattens_eight_wide_too():
+    """fcgpu_options.bvh_width = 8 (Node8: octant-ordered child slots, consecutive interior children, consecutive leaf
+    records): every stand-in scene flattens on the host, with fewer nodes than 4-wide and the few group entries its
+    traversal stack needs; a chain-shaped hierarchy deeper than the 15 entries is reported, not built wrong."""
+    for name, build in S.BUILDERS.items():
+        sc = S.random_scene(1, 32, 24) if name == "random_scene" else build(width=32, height=24)
+        four, eight = R.check_scene(sc), R.check_scene(sc, bvh_width=8)
+        assert eight.primitives == four.primitives == sc.primitive_total(), name
+        assert 0 < eight.wide_nodes <= four.wide_nodes and eight.max_stack <= four.max_stack, name
+    room = S.room(width=64, height=36, tess=64)
+    four, eight = R.check_scene(room), R.check_scene(room, bvh_width=8)
+    assert (four.wide_nodes, four.max_stack) == (12112, 28) and (eight.wide_nodes, eight.max_stack) == (8459, 5)
+    assert R.check_scene(ribbon_scene(420), bvh_width=8).max_stack > 15  # the upload refuses it (FCGPU_E_LIMIT): GPU test
+
+
 def test_card_scenes_straddle_the_lds_stack_capacity():
     """The GPU tests of the 28 .. 32-entry window (test_bvh_whose_stack_need_is_at_the_lds_capacity) and of the
     no-allocation entry point (47 of its 62 entries) rely on these depths; fcgpu_check_scene builds the same hierarchy."""
