@@ -316,6 +316,27 @@ namespace fcg
         }
     }
 
+#ifdef FCG_TRI_REFINE
+    // Experiment (tools/build_variant.sh -DFCG_TRI_REFINE): (t, b0, b1) of the ACCEPTED triangle hit recomputed in double
+    // from the same float ray and float vertices, once per ray (see DESIGN.md section 4 for what it measured)
+    FC_D void refine_hit_f64(const SceneDev<float>& S, Trav<float>& T)
+    {
+        if(T.pk == INVALID_U32 || (T.pk >> 30) != KIND_TRI) return;
+        const TriRec& tr = S.tris[T.pk & 0x3FFFFFFFu];
+        const RayCtx<double> rc = make_ray(vec3<double>{double(T.rc.o.x), double(T.rc.o.y), double(T.rc.o.z)},
+                                           vec3<double>{double(T.rc.d.x), double(T.rc.d.y), double(T.rc.d.z)});
+        double t, b0, b1;
+        if(tri_intersect<double>(tr, rc, consts<double>::inf, t, b0, b1))
+        {
+            T.t_max = static_cast<float>(t);
+            T.b0 = static_cast<float>(b0);
+            T.b1 = static_cast<float>(b1);
+        }
+    }
+    template<typename TT> FC_D void refine_hit_f64(const SceneDev<double>&, TT&) {}
+    FC_D void refine_hit_f64(const SceneDev<float>&, Trav8<float>&) {}
+#endif
+
     // the material's parameters at (u, v): image textures where it has them (x of the texel for the scalar
     // ones, image_texture_2d_r), its constants elsewhere
     template<typename R>
@@ -407,6 +428,9 @@ namespace fcg
                     const uint32_t ext_in = M.ext;
                     if(T.pk != INVALID_U32)
                     {
+#ifdef FCG_TRI_REFINE
+                        refine_hit_f64(S, T);
+#endif
                         hit_point(S, T.rc, T.pk, T.t_max, T.b0, T.b1, p, nrm, prim, entity, key_hint);
                         // a hinted triangle is no medium boundary and has one constant lobe: the record just loaded decides
                         const uint32_t med = key_hint != KEY_HINT_NONE ? 0u : static_cast<uint32_t>(S.entities[entity].medium);

@@ -809,6 +809,39 @@ namespace fcg
         return mine;
     }
 
+    // object-space point where the float ray meets the sphere P, in double arithmetic (same root choice as sphere_intersect;
+    // `t32` = the root the fp32 test accepted, used when the double solve finds none: a grazing hit)
+    FC_D vec3<float> sphere_point_f64(const XPrim<float>& P, const RayCtx<float>& rc, float t32)
+    {
+        // one object-space component at a time (and once more for the point): few doubles live at once, so that the finish
+        // phase of k_extend stays within the registers of five waves per SIMD
+        auto comp_o = [&](int i) { return double(P.inv[4 * i]) * double(rc.o.x) + double(P.inv[4 * i + 1]) * double(rc.o.y) + double(P.inv[4 * i + 2]) * double(rc.o.z) + double(P.inv[4 * i + 3]); };
+        auto comp_d = [&](int i) { return double(P.inv[4 * i]) * double(rc.d.x) + double(P.inv[4 * i + 1]) * double(rc.d.y) + double(P.inv[4 * i + 2]) * double(rc.d.z); };
+        double a = 0.0, hb = 0.0, c = -double(P.a) * double(P.a);
+#pragma unroll
+        for(int i = 0; i < 3; ++i)
+        {
+            const double o = comp_o(i), d = comp_d(i);
+            a += d * d;
+            hb += o * d;
+            c += o * o;
+        }
+        const double b = 2.0 * hb;
+        const double disc = b * b - 4.0 * a * c;
+        double t = double(t32);
+        if(disc >= 0.0)
+        {
+            const double sq = sqrt(disc);
+            const double q = b < 0.0 ? -0.5 * (b - sq) : -0.5 * (b + sq);
+            const double t0 = q / a, t1 = c / q;
+            // the root nearest to the one the fp32 test took (it chose the first non-negative one)
+            const double pick = fabs(t0 - double(t32)) <= fabs(t1 - double(t32)) ? t0 : t1;
+            if(pick == pick) t = pick;
+        }
+        return vec3<float>{static_cast<float>(comp_o(0) + comp_d(0) * t), static_cast<float>(comp_o(1) + comp_d(1) * t), static_cast<float>(comp_o(2) + comp_d(2) * t)};
+    }
+    template<typename R> FC_D vec3<R> sphere_point_f64(const XPrim<R>&, const RayCtx<R>&, R) { return vec3<R>{}; }  // (never called for R = double)
+
     // geometry of a hit: world position and geometric normal, as the reference's raycast_surface_point builds them
     template<typename R>
     FC_D void hit_point(const SceneDev<R>& S, const RayCtx<R>& rc, uint32_t pk, R t, R b0, R b1, vec3<R>& p, vec3<R>& n,
@@ -832,6 +865,14 @@ namespace fcg
             const XPrim<R>& P = S.xprims[idx];
             vec3<R> ol = xf_point(P.inv, rc.o), dl = xf_dir(P.inv, rc.d);
             vec3<R> pl = ol + dl * t;
+            if constexpr(sizeof(R) == 4)
+            {
+                // fp32: the object-space hit point of a SPHERE solved once more in double from the same float ray (the
+                // accepted hit only, once per ray). In fp32 the quadratic cancels (b^2 - 4ac = 1024 - 1008 for the room's
+                // spheres seen from the camera) and leaves 4e-6 in t, i.e. 2e-6 in the normal of a radius-2 sphere, which a
+                // mirror bounce carries to the walls: measured on the 1080p smooth-mirror crop.
+                if(kind == KIND_SPHERE) pl = sphere_point_f64(P, rc, t);
+            }
             p = xf_point(P.fwd, pl);                      // sphere_surface.hpp:123-126, plane_surface.hpp:79-88
             if(kind == KIND_SPHERE)
                 n = xf_dir(P.fwd, normalize(pl));         // sphere_surface.hpp:127

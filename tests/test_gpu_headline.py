@@ -23,31 +23,34 @@ import os
 import numpy as np
 import pytest
 
+import bench
 from common import CROP_FIXTURES, divergence_table, load_crop, pixel_rel_err, render_crop
 
 pytestmark = pytest.mark.gpu
 
 # crop -> (median rel err <=, within 1e-2 >=, within 1e-3 >=, |mean ratio - 1| <=); measured on MI355X (round 3) in the comments.
-# The smooth mirror is the hardest: every path of the crop is mirrored by the curved sphere onto the tessellated walls, so
-# the few ulps of its first hit decide more often than elsewhere on which side of a triangle edge the second hit lands
-# (2.1e-2 of its paths diverge, 99.8 % of them that way: test_crop_f32_residue_is_attributed).
+# The headline crop's bar IS bench.py's parity gate (one bar, stated there). Round 3 solved the hit point of an accepted SPHERE
+# hit in double (fc_traverse.h: sphere_point_f64): the fp32 quadratic left 4e-6 in t, which the curved spheres of the room
+# turned into hits on the wrong side of a triangle edge one bounce later; before that the same crops measured 0.989 / 0.957 /
+# 0.985 / 0.984 within 1e-2. The smooth mirror stays the hardest: every path of the crop is mirrored by the sphere onto the walls.
 F32_BARS = {
-    "headline": (2e-6, 0.985, 0.97, 5e-4),           # 5.4e-7, 0.9886, 0.9756, 3.4e-5
-    "c3_smooth_mirror": (3e-6, 0.95, 0.905, 5e-4),   # 7.6e-7, 0.9571, 0.9155, 5.0e-5
-    "c3_smooth_glass": (2e-6, 0.98, 0.96, 5e-4),     # 4.8e-7, 0.9845, 0.9678, 3.7e-5
-    "c3_plastic": (3e-6, 0.978, 0.94, 5e-4),         # 6.7e-7, 0.9838, 0.9499, 4.7e-5
+    "headline": (bench.PARITY_MEDIAN_REL_ERR, bench.PARITY_WITHIN_1E2_MIN_16SPP, bench.PARITY_WITHIN_1E3_MIN_16SPP, bench.PARITY_MEAN_RATIO),
+                                                     # 3.9e-7, 0.9970, 0.9923, 1.6e-5
+    "c3_smooth_mirror": (2e-6, 0.99, 0.978, 3e-4),   # 5.1e-7, 0.9940, 0.9846, 1.0e-5
+    "c3_smooth_glass": (2e-6, 0.994, 0.987, 3e-4),   # 3.1e-7, 0.9969, 0.9919, 4e-6
+    "c3_plastic": (2e-6, 0.994, 0.986, 3e-4),        # 4.1e-7, 0.9970, 0.9906, 1.7e-5
     "c4_mask": (4e-6, 0.988, 0.945, 5e-4),           # 1.1e-6, 0.9924, 0.9549, 1.7e-4
 }
 # crop -> (diverged paths <=, share of first divergences that are a closest hit on another primitive >=, pixels beyond 1e-2
 # that hold neither a diverged path nor a visibility difference <=); measured in the comments.
 # c4_mask: its 160 unattributed pixels are not decisions but the roughness MAP: an fp32 camera ray lands ~1e-4 texels from the
 # fp64 one, the 1024^2 roughness map has 35 % texel-to-texel contrast (noise), and GGX's D follows roughness to the
-# fourth power: ablation per texture in DESIGN.md section 4 (only the roughness map reproduces it; double-precision
-# texture coordinates and barycentrics do not remove it, the ray itself is the fp32 quantity).
+# fourth power: ablation per texture in DESIGN.md section 4 (only the roughness and normal maps reproduce it, with a box
+# filter it is gone; double-precision texture coordinates and barycentrics do not remove it: the ray itself is the fp32 quantity).
 DIVERGENCE_BARS = {
-    "headline": (7e-3, 0.95, 0),            # 5.3e-3, 0.989, 0
-    "c3_smooth_mirror": (2.6e-2, 0.99, 0),  # 2.08e-2, 0.998, 0
-    "c4_mask": (2e-3, 0.85, 260),           # 7.0e-4, 0.937, 160 of 32 400
+    "headline": (3e-3, 0.95, 0),            # 1.94e-3, 0.973, 0
+    "c3_smooth_mirror": (6e-3, 0.97, 0),    # 4.27e-3, 0.989, 0
+    "c4_mask": (2e-3, 0.85, 260),           # 7.3e-4, 0.937, 160 of 32 400
 }
 
 

@@ -145,18 +145,25 @@ def test_radiance_f32_within_stated_tolerance(name):
     assert abs(rgb.mean() - ref.mean()) <= 0.005 * ref.mean()
 
 
-def test_f32_matches_f32_restatement_statistically():
-    """GPU fp32 vs the float instantiation of the CPU oracle (same epsilon, same streams)."""
+@pytest.mark.parametrize("offset", ["along_ray", "normal"])
+def test_f32_matches_f32_restatement_statistically(offset):
+    """GPU fp32 vs the float instantiation of the CPU oracle (same epsilon, same streams), with the fp32 default origin
+    offset (along the ray: the restatement mirrors that deviation, so this leg checks the device against a copy of its
+    own rule) and with the reference's own rule (along the normal: the restatement then is the reference's algorithm in
+    float). Measured: median 4.2e-7, 99.96 % within 1e-2, 98.8 % within 1e-4 in both. What bounds fp32 against the REAL
+    reference are the film fixtures above (every scene class: zoo, glass, nested media, textures ...) and the crops of
+    tests/test_gpu_headline.py."""
     scene = S.room(width=64, height=36, tess=4)
-    o = pyref.restatement("f32").scene(scene)
+    o = pyref.restatement("f32").scene(scene, along_ray=offset == "along_ray")
     ref, n, _ = o.render(4, seed=2, threads=4)
-    with make_ctx(scene, "f32") as ctx:
+    with make_ctx(scene, "f32", origin_offset=offset) as ctx:
         ctx.set_sampler(2)
         ctx.render_pass(0, 4)
         rgb, m = ctx.read_film()
     assert n == m
     rel = pixel_rel_err(rgb, ref)
-    assert np.median(rel) <= 1e-4 and (rel <= 1e-2).mean() >= 0.9
+    print(f"fp32 device vs fp32 restatement ({offset}): median {np.median(rel):.2e}, within 1e-2 {(rel <= 1e-2).mean():.4f}, within 1e-4 {(rel <= 1e-4).mean():.4f}")
+    assert np.median(rel) <= 2e-6 and (rel <= 1e-2).mean() >= 0.998 and (rel <= 1e-4).mean() >= 0.97
 
 
 def test_converged_image_relmse():
