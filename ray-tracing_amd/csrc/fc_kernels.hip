@@ -362,6 +362,17 @@ namespace fcg
     // TEX: the scene has materials with image textures (per-hit lobe construction compiled in: +5 % shade time, so
     // scenes without them run the instantiations without it)
     // FCG_EXTEND_WAVES (experiment, tools/build_variant.sh): makes the compiler fit k_extend into the registers of that many waves per SIMD
+#ifndef FCG_EXTEND_SPEC
+#define FCG_EXTEND_SPEC 0
+#endif
+#ifndef FCG_SHADOW_SPEC
+#define FCG_SHADOW_SPEC 0
+#endif
+#ifdef FCG_SHADOW_WAVES
+#define FCG_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(FCG_SHADOW_WAVES, FCG_SHADOW_WAVES)))
+#else
+#define FCG_SHADOW_ATTR
+#endif
 #ifdef FCG_EXTEND_WAVES
 #define FCG_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(FCG_EXTEND_WAVES, FCG_EXTEND_WAVES)))
 #else
@@ -595,7 +606,7 @@ namespace fcg
             if constexpr(WIDE8)
                 trav_round8<R, false, BLOCK>(S, T, stack, n_overflow, B.descend_min, n_nodes, n_prims);
             else
-                trav_round<R, false, BLOCK, SPILL, PROF>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims, ph);
+                trav_round<R, false, BLOCK, SPILL, PROF, FCG_EXTEND_SPEC != 0>(S, T, stack, nodebuf, n_overflow, B.descend_min, n_nodes, n_prims, ph);
             n_rounds += 1;
         }
         if(PROF)
@@ -1139,7 +1150,7 @@ namespace fcg
 
     // ------------------------------------------------------------------ shadow
     template<typename R, bool SPILL, bool WIDE8 = false>
-    __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    __global__ __launch_bounds__(BLOCK) FCG_SHADOW_ATTR void k_shadow(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
         __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[FCG_TREELET ? FCG_TREELET * 64 : WAVES * NODEBUF_WAVE];
@@ -1192,7 +1203,7 @@ namespace fcg
             if constexpr(WIDE8)
                 trav_round8<R, true, BLOCK>(S, T, stack, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
             else
-                trav_round<R, true, BLOCK, SPILL>(S, T, stack, nodebuf, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
+                trav_round<R, true, BLOCK, SPILL, false, FCG_SHADOW_SPEC != 0>(S, T, stack, nodebuf, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
         }
         wave_stat_add(Q.stats, ST_SHADOW, n_cast);
         wave_stat_add(Q.stats, ST_OCCLUDED, n_occ);
@@ -1340,7 +1351,7 @@ namespace fcg
     hipError_t noalloc_scratch_for_device(int device, unsigned char** out)
     {
         constexpr int MAX_DEVICES = 64;  // beyond it: no scratch address, i.e. no fcgpu_trace_closest_noalloc on that device (everything else works)
-        static_assert(STACK_CAP + static_cast<int>(NOALLOC_SPILL_ENTRIES) == FCGPU_NOALLOC_MAX_STACK, "include/fcgpu.h states the limit the kernel has");
+        static_assert(STACK_CAP != 30 || STACK_CAP + static_cast<int>(NOALLOC_SPILL_ENTRIES) == FCGPU_NOALLOC_MAX_STACK, "include/fcgpu.h states the limit the shipped kernel has (other -DFCG_STACK_CAP values are tools/build_variant.sh experiments)");
         static_assert(static_cast<int>(NOALLOC_SPILL_ENTRIES) <= STACK_SPILL_MAX, "the kernel bounds spill pushes by STACK_SPILL_MAX: the static columns must hold that many");
         static std::mutex lock;
         static unsigned char* address[MAX_DEVICES] = {};

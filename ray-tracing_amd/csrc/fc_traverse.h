@@ -258,7 +258,19 @@ namespace fcg
         }
         else
         {
-            // deep tree: entries beyond STACK_CAP go to this lane's column of the spill buffer
+            // deep tree: entries beyond STACK_CAP go to this lane's column of the spill buffer; while three entries are free
+            // in LDS (nearly always: the worst case is a bound over all rays) the pushes are those of the plain kernel
+            if(sp <= STACK_CAP - 3)
+            {
+#pragma unroll
+                for(int k = 3; k >= 1; --k)
+                {
+                    const bool push = key[k] != INVALID_U32;
+                    if(push) stack[sp * STRIDE] = ch[k];
+                    sp += push ? 1 : 0;
+                }
+            }
+            else
 #pragma unroll
             for(int k = 3; k >= 1; --k)
             {
@@ -343,6 +355,7 @@ namespace fcg
         R b0, b1;
         uint32_t pk;
         uint32_t cur;  // interior node index, leaf word, or INVALID_U32 = nothing left (leaf bit set)
+        uint32_t post; // SPEC rounds: a leaf reached but not tested yet (the lane went on descending), else INVALID_U32
         int sp;
     };
 
@@ -354,9 +367,10 @@ namespace fcg
         T.b1 = R(0);
         T.pk = INVALID_U32;
         T.cur = 0;  // root is always a wide node
+        T.post = INVALID_U32;
         T.sp = 0;
     }
-    template<typename R> FC_D bool trav_done(const Trav<R>& T) { return T.cur == INVALID_U32; }
+    template<typename R> FC_D bool trav_done(const Trav<R>& T) { return T.cur == INVALID_U32 && T.post == INVALID_U32; }
 
     // One round of the while-while traversal for the whole wave: every lane that holds an interior
     // node descends until it holds a leaf (the descent loop ends early once fewer than DESCEND_MIN
@@ -371,7 +385,10 @@ namespace fcg
     // per wave: wave_stat_add_uniform). n_prims: this lane's primitive tests.
     // PROF (development aid): ph[0] += clock cycles in the descent loop, ph[1] += cycles in the leaf
     // phase, ph[2] += wave-level descent trips, ph[3] += leaf phases entered, ph[6] += lanes holding a leaf in them.
-    template<typename R, bool ANY, int STRIDE, bool SPILL, bool PROF = false>
+    // SPEC (speculative descent, after Aila & Laine 2009): a lane that reaches a leaf parks it in T.post and goes on with the
+    // next entry of its stack instead of idling until the wave's leaf phase; it waits only once it holds a second leaf (or its
+    // stack is empty). The primitives tested are the same for an ANY ray that is not occluded (nothing shrinks its t_max).
+    template<typename R, bool ANY, int STRIDE, bool SPILL, bool PROF = false, bool SPEC = false>
     FC_D void trav_round(const SceneDev<R>& S, Trav<R>& T, uint32_t* stack, unsigned char* nodebuf, StackStats& overflow, int descend_min,
                          uint32_t& n_nodes, uint32_t& n_prims, unsigned long long* ph = nullptr)
     {
@@ -379,8 +396,9 @@ namespace fcg
         if(PROF) c0 = clock64();
         uint32_t* spill = SPILL ? S.stack_spill + (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) : nullptr;
         uint32_t cur = T.cur;
+        uint32_t post = SPEC ? T.post : INVALID_U32;
         int sp = T.sp;
-        bool leaf_waiting = __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
+        bool leaf_waiting = SPEC ? __ballot(post != INVALID_U32) != 0ull : __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
         for(;;)
         {
             const bool descending = !child_is_leaf(cur);
@@ -436,24 +454,35 @@ namespace fcg
             }
             if(!PROF) n_nodes += __popcll(dm);  // node steps of the whole wave, counted on the scalar unit
             if(!SPILL) overflow.lost += __popcll(__ballot(lost_push));
-            leaf_waiting = leaf_waiting || __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
+            if(SPEC)
+            {
+                if(post == INVALID_U32 && child_is_leaf(cur) && cur != INVALID_U32)
+                {
+                    post = cur;
+                    cur = sp > 0 ? stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
+                }
+                leaf_waiting = leaf_waiting || __ballot(post != INVALID_U32) != 0ull;
+            }
+            else
+                leaf_waiting = leaf_waiting || __ballot(child_is_leaf(cur) && cur != INVALID_U32) != 0ull;
         }
         unsigned long long c1 = 0;
         if(PROF)
         {
             c1 = clock64();
             ph[0] += c1 - c0;
-            const uint64_t lm = __ballot(child_is_leaf(cur) && cur != INVALID_U32);
+            const uint64_t lm = SPEC ? __ballot(post != INVALID_U32) : __ballot(child_is_leaf(cur) && cur != INVALID_U32);
             ph[3] += lm != 0ull ? 1 : 0;
             ph[6] += __popcll(lm);
         }
-        if(child_is_leaf(cur) && cur != INVALID_U32)
+        const uint32_t leaf = SPEC ? post : cur;
+        if(child_is_leaf(leaf) && leaf != INVALID_U32)
         {
-            const uint32_t first = leaf_first(cur), kind = leaf_kind(cur);
+            const uint32_t first = leaf_first(leaf), kind = leaf_kind(leaf);
             bool stop = false;
             if(kind == KIND_TRI)
             {
-                const uint32_t count = leaf_count(cur);
+                const uint32_t count = leaf_count(leaf);
                 n_prims += count;
                 // all records of the leaf are requested before the first test: one memory latency per
                 // leaf instead of one per triangle
@@ -489,9 +518,23 @@ namespace fcg
                     if(ANY) stop = true;
                 }
             }
-            cur = (!stop && sp > 0) ? stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
+            if(SPEC)
+            {
+                // the parked leaf is done; a second leaf the lane was waiting with takes its place
+                post = INVALID_U32;
+                if(stop)
+                    cur = INVALID_U32;
+                else if(child_is_leaf(cur) && cur != INVALID_U32)
+                {
+                    post = cur;
+                    cur = sp > 0 ? stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
+                }
+            }
+            else
+                cur = (!stop && sp > 0) ? stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
         }
         T.cur = cur;
+        if(SPEC) T.post = post;
         T.sp = sp;
         if(PROF) ph[1] += clock64() - c1;
     }
@@ -536,6 +579,7 @@ namespace fcg
     template<typename R> FC_D void trav_idle(Trav<R>& T)
     {
         T.cur = INVALID_U32;
+        T.post = INVALID_U32;
         T.sp = 0;
     }
 
@@ -735,6 +779,7 @@ namespace fcg
         T.b1 = R(0);
         T.pk = INVALID_U32;
         T.cur = active ? 0u : INVALID_U32;
+        T.post = INVALID_U32;
         T.sp = 0;
         uint32_t nn = 0, np = 0;
         while(__ballot(!trav_done(T)) != 0ull) trav_round<R, ANY, STRIDE, SPILL>(S, T, stack, nodebuf, overflow, 12, nn, np);

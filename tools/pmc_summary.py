@@ -19,7 +19,8 @@ for f in glob.glob(f"{out}/**/*counter_collection.csv", recursive=True):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         agg[k]["_dispatches_" + r["Counter_Name"]] += 1.0
 rays = json.load(open(f"{out}/rays.json")) if glob.glob(f"{out}/rays.json") else {}
-names = {"k_extend<float, false, false, false>": ("k_extend", "closest_rays"), "k_shadow<float, false>": ("k_shadow", "shadow_rays"),
+# the instantiations the bench workload runs: no profiling, no spill, no textures, 4-wide hierarchy
+names = {"k_extend<float, false, false, false, false>": ("k_extend", "closest_rays"), "k_shadow<float, false, false>": ("k_shadow", "shadow_rays"),
          "k_shade<float, 0, false>": ("k_shade_lambert", "closest_rays")}
 kern = {}
 for k, (short, unit) in names.items():
@@ -40,6 +41,9 @@ for k, (short, unit) in names.items():
             e["fabric_bytes_per_ray"] = b / rays[unit]
     if e:
         kern[short] = e
+missing = [short for short, _ in names.values() if short not in kern]
+if missing:
+    sys.exit(f"pmc_summary: no counters for {missing}: kernel names in the passes: {sorted(passes.get('sq', {}))}")
 # the counters describe the kernels of THIS tree: bench.py refuses to print them beside the timing of another build
 build = importlib.import_module("ray-tracing_amd.buildinfo").kernel_source_hash()
 print(json.dumps({"source": source, "build": build, "batch_paths": batch, "rays": rays, "kernels": kern}, indent=1))
