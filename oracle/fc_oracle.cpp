@@ -6,13 +6,45 @@
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <thread>
 
 namespace fco
 {
     // 0 = random stream; else stratified_sampler{count, seed} analogue (fcgpu_sampler.h); set through *_set_stratified
     static uint32_t g_stratified_count = 0;
+
+    // Conditioning probe (tools/ulp_sensitivity.py): with a non-zero seed every transcendental result is moved by -1, 0 or +1
+    // unit in the last place, chosen by a hash of the argument and the seed. The device's libm and glibc differ by that
+    // much; a pixel whose value moves by 1e-9 under this noise is ill-conditioned, not wrong. 0 (default) = off: the plain libm.
+    static std::atomic<uint64_t> g_ulp_noise{0};
+
+    namespace lm
+    {
+        template<typename R> inline R nudge(R y, R x)
+        {
+            const uint64_t seed = g_ulp_noise.load(std::memory_order_relaxed);
+            if(seed == 0 || !(y == y) || y == R(0)) return y;
+            double xd = static_cast<double>(x);
+            uint64_t h;
+            std::memcpy(&h, &xd, sizeof h);
+            h = (h ^ seed) * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 32;
+            const int k = static_cast<int>(h % 3u) - 1;
+            return k == 0 ? y : std::nextafter(y, k > 0 ? std::numeric_limits<R>::infinity() : -std::numeric_limits<R>::infinity());
+        }
+        template<typename R> inline R sin(R x) { return nudge(std::sin(x), x); }
+        template<typename R> inline R cos(R x) { return nudge(std::cos(x), x); }
+        template<typename R> inline R tan(R x) { return nudge(std::tan(x), x); }
+        template<typename R> inline R exp(R x) { return nudge(std::exp(x), x); }
+        template<typename R> inline R acos(R x) { return nudge(std::acos(x), x); }
+        template<typename R> inline R pow(R x, R y) { return nudge(std::pow(x, y), x); }
+        template<typename R> inline R atan2(R y, R x) { return nudge(std::atan2(y, x), y + x); }
+    }
 
     namespace
     {
@@ -48,22 +80,22 @@ namespace fco
         Mat rotate_x(double t)  // math.hpp:473-484
         {
             Mat r = identity();
-            r.m[1][1] = std::cos(t); r.m[1][2] = -std::sin(t);
-            r.m[2][1] = std::sin(t); r.m[2][2] = std::cos(t);
+            r.m[1][1] = lm::cos(t); r.m[1][2] = -lm::sin(t);
+            r.m[2][1] = lm::sin(t); r.m[2][2] = lm::cos(t);
             return r;
         }
         Mat rotate_y(double t)  // math.hpp:486-497
         {
             Mat r = identity();
-            r.m[0][0] = std::cos(t); r.m[0][2] = std::sin(t);
-            r.m[2][0] = -std::sin(t); r.m[2][2] = std::cos(t);
+            r.m[0][0] = lm::cos(t); r.m[0][2] = lm::sin(t);
+            r.m[2][0] = -lm::sin(t); r.m[2][2] = lm::cos(t);
             return r;
         }
         Mat rotate_z(double t)  // math.hpp:499-510
         {
             Mat r = identity();
-            r.m[0][0] = std::cos(t); r.m[0][1] = -std::sin(t);
-            r.m[1][0] = std::sin(t); r.m[1][1] = std::cos(t);
+            r.m[0][0] = lm::cos(t); r.m[0][1] = -lm::sin(t);
+            r.m[1][0] = lm::sin(t); r.m[1][1] = lm::cos(t);
             return r;
         }
 
@@ -179,7 +211,7 @@ namespace fco
                     else if(im.format == FCGPU_IMAGE_SRGB8)
                     {
                         double x = b[3 * i + c] / 255.0;
-                        v = x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4);
+                        v = x <= 0.04045 ? x / 12.92 : lm::pow((x + 0.055) / 1.055, 2.4);
                     }
                     else
                     {
@@ -319,7 +351,7 @@ namespace fco
             for(int i = 0; i < ny; ++i)
             {
                 std::vector<double> row;
-                double sin_theta = std::sin(PI * (i + 0.5) / ny);
+                double sin_theta = lm::sin(PI * (i + 0.5) / ny);
                 for(int j = 0; j < nx; ++j)
                 {
                     V3<double> in = integrate(j / static_cast<double>(nx), i / static_cast<double>(ny), (j + 1) / static_cast<double>(nx),
@@ -335,8 +367,8 @@ namespace fco
         void uv_of(V3<R> wi, R& u, R& v, R& theta) const  // :58-65
         {
             V3<R> w = xf.inv_dir(wi);
-            theta = std::acos(std::clamp(w.y, R(-1), R(1)));
-            R p = std::atan2(w.z, w.x);
+            theta = lm::acos(std::clamp(w.y, R(-1), R(1)));
+            R p = lm::atan2(w.z, w.x);
             R phi = p < R(0) ? p + R(2) * R(PI) : p;
             v = theta / R(PI);
             u = R(1) - phi / (R(2) * R(PI));
@@ -351,7 +383,7 @@ namespace fco
         {
             R u, v, theta;
             uv_of(wi, u, v, theta);
-            R sin_theta = std::sin(theta);
+            R sin_theta = lm::sin(theta);
             if(sin_theta == R(0)) return R(0);
             size_t iy, ix;
             double py = marginal.pdf_continuous(static_cast<double>(v), iy);  // distribution_2d::pdf_continuous, :154-160
@@ -366,11 +398,11 @@ namespace fco
             rows[iy].sample_continuous(static_cast<double>(ux), sx, pdf_x, ix);
             R su = R(sx), sv = R(sy);
             R theta = sv * R(PI), phi = (R(1) - su) * R(2) * R(PI);
-            R cos_theta = std::cos(theta), sin_theta = std::sin(theta);
+            R cos_theta = lm::cos(theta), sin_theta = lm::sin(theta);
             if(sin_theta == R(0)) return false;
             Li = evaluate<R>(su, sv) * strength;
             if(!nonzero(Li)) return false;
-            wi = xf.dir(V3<R>{sin_theta * std::cos(phi), cos_theta, sin_theta * std::sin(phi)});
+            wi = xf.dir(V3<R>{sin_theta * lm::cos(phi), cos_theta, sin_theta * lm::sin(phi)});
             pdf = R(pdf_x * pdf_y) / (R(2) * R(PI) * R(PI) * sin_theta);
             return true;
         }
@@ -488,7 +520,7 @@ namespace fco
             cam = d.camera;
             cam_xf = convert<R>(make_transform(cam.position, cam.rotation, nullptr));
             double f = cam.lens_radius == 0.0 ? 1.0 : cam.focus_distance;
-            double px = 2.0 * f * std::tan(cam.fov / 2.0) / static_cast<double>(cam.height);
+            double px = 2.0 * f * lm::tan(cam.fov / 2.0) / static_cast<double>(cam.height);
             pixel_size = static_cast<R>(px);
             plane_w = static_cast<R>(cam.width * px);
             plane_h = static_cast<R>(cam.height * px);
@@ -771,9 +803,9 @@ namespace fco
                 *sp = Point<R>{};
                 sp->position = s.xf.point(pos);
                 sp->normal = s.xf.dir(normalize(pos));
-                R phi = std::atan2(pos.z, pos.x);
+                R phi = lm::atan2(pos.z, pos.x);
                 if(phi <= R(0)) phi += R(PI) * R(2);
-                V3<R> tangent{-std::sin(phi), R(0), std::cos(phi)};
+                V3<R> tangent{-lm::sin(phi), R(0), lm::cos(phi)};
                 sp->shading_normal = sp->normal;
                 sp->tangent = tangent;
                 sp->bitangent = cross(tangent, sp->normal);
@@ -1028,8 +1060,8 @@ namespace fco
             r = oy;
             theta = R(PI) / R(2) - R(PI) * ox / (R(4) * oy);
         }
-        x = r * std::cos(theta);
-        y = r * std::sin(theta);
+        x = r * lm::cos(theta);
+        y = r * lm::sin(theta);
     }
     template<typename R> V3<R> hemisphere_cosine(R ux, R uy)  // sampling.hpp:31-35
     {
@@ -1042,7 +1074,7 @@ namespace fco
         R z = R(1) - R(2) * ux;
         R r = std::sqrt(std::max(R(0), R(1) - z * z));
         R phi = R(2) * R(PI) * uy;
-        return {r * std::cos(phi), z, r * std::sin(phi)};
+        return {r * lm::cos(phi), z, r * lm::sin(phi)};
     }
 
     // smith_ggx_microfacet_model, microfacet.hpp:21-82
@@ -1058,7 +1090,7 @@ namespace fco
             V3<R> T2 = cross(T1, ih);
             R r = std::sqrt(ux);
             R phi = R(2) * R(PI) * uy;
-            R t1 = r * std::cos(phi), t2 = r * std::sin(phi);
+            R t1 = r * lm::cos(phi), t2 = r * lm::sin(phi);
             R s = R(0.5) * (R(1) + ih.y);
             t2 = (R(1) - s) * std::sqrt(R(1) - t1 * t1) + s * t2;
             V3<R> Nh = t1 * T1 + t2 * T2 + std::sqrt(std::max(R(0), R(1) - t1 * t1 - t2 * t2)) * ih;
@@ -1798,7 +1830,7 @@ namespace fco
         {
             if(m.vacuum) return {R(1), R(1), R(1)};
             V3<R> e = -m.color * m.density * length(b - a);
-            return {std::exp(e.x), std::exp(e.y), std::exp(e.z)};
+            return {lm::exp(e.x), lm::exp(e.y), lm::exp(e.z)};
         }
 
         // const_diffuse_area_light::get_Le, const_diffuse_area_light.hpp:20-26
@@ -2228,6 +2260,7 @@ namespace fco
     extern "C" void PREFIX##_set_epsilon(void* h, double e) { static_cast<fco::Handle<R>*>(h)->scene->epsilon = static_cast<R>(e); }               \
     extern "C" void PREFIX##_set_offset_along_ray(void* h, int on) { static_cast<fco::Handle<R>*>(h)->scene->offset_along_ray = on != 0; }         \
     extern "C" void PREFIX##_set_stratified(uint32_t count) { fco::g_stratified_count = count; }                                                  \
+    extern "C" void PREFIX##_set_ulp_noise(uint64_t seed) { fco::g_ulp_noise.store(seed); }                                                       \
     extern "C" int PREFIX##_render(void* h, int integ, int mpl, int vis, uint64_t seed, uint32_t sb, uint32_t sc, int x0, int y0, int w, int hh,     \
                                    int threads, double* rgb, uint64_t* cnt, fco::Stats* st, fco::RayRecord* log, uint64_t cap, uint64_t* nlog)       \
     {                                                                                                                                             \

@@ -65,6 +65,13 @@ class _Backend:
     def scene(self, scene, epsilon=None, along_ray=None):
         return _Scene(self, scene, epsilon, self.along_ray if along_ray is None else along_ray)
 
+    def set_ulp_noise(self, seed):
+        """Restatement only (fc_oracle.cpp: lm::nudge): seed != 0 moves every transcendental result by -1 / 0 / +1 ulp, the
+        distance between two correct libms; how far a pixel follows that noise is its conditioning. 0 = off."""
+        f = self._fn("_set_ulp_noise")
+        f.argtypes, f.restype = [C.c_uint64], None
+        f(int(seed))
+
     def bsdf_table(self, material, queries, ng=(0, 1, 0), tangent=(1, 0, 0), ns=(0, 1, 0), bitangent=(0, 0, 1),
                    eta_a=1.0, eta_b=1.0):
         q = np.ascontiguousarray(queries, dtype=bsdf_query_dtype)

@@ -93,3 +93,22 @@ def test_f32_restatement_is_close_to_f64(oracle):
     a, n, _ = pyref.restatement("f32").scene(scene).render(int(z["spp"]), seed=int(z["seed"]), threads=4)
     ref = z["mis_rgb_sum"]
     assert abs(a.mean() - ref.mean()) < 0.02 * ref.mean()
+
+
+def test_ulp_noise_probe_is_off_by_default_and_small_when_on(oracle):
+    """tools/ulp_sensitivity.py's hook: transcendental results moved by -1 / 0 / +1 ulp. Off: the fixture bit for bit as
+    before; on: the image moves by rounding noise only (a pixel that moves by more is ill-conditioned, which is what the tool
+    is for), and switching it off restores the plain result."""
+    z, scene = load_film("zoo")
+    sc = oracle.scene(scene)
+    args = dict(max_path_length=int(z["max_path_length"]), seed=int(z["seed"]), threads=4, stratified=film_stratified(z))
+    plain, _, _ = sc.render(int(z["spp"]), **args)
+    oracle.set_ulp_noise(7)
+    try:
+        noisy, _, _ = sc.render(int(z["spp"]), **args)
+    finally:
+        oracle.set_ulp_noise(0)
+    again, _, _ = sc.render(int(z["spp"]), **args)
+    assert np.array_equal(plain, again)
+    assert not np.array_equal(plain, noisy)
+    assert np.abs(noisy - plain).max() <= 1e-9 * np.abs(plain).max()

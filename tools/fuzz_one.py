@@ -1,4 +1,4 @@
-"""Development tool: one random scene, GPU fp64 with both hierarchy builders against the CPU restatement.
+"""Development tool: one random scene, GPU fp64 with every hierarchy builder and both node widths against the CPU restatement.
 usage: python tools/fuzz_one.py SEED"""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,13 +13,15 @@ sc = S.random_scene(seed, 32, 24)
 o = pyref.restatement("f64").scene(sc)
 ref, n, st = o.render(3, max_path_length=8, seed=seed, threads=8)
 print("restatement closest", st.closest_rays, "shadow", st.any_rays, "occluded", st.any_occluded, "nan", st.nan_samples)
-for builder in ("host", "device"):
+for builder, width in (("host", 4), ("device", 4), ("host", 8), ("reference", 4)):
     with R.GpuContext(0) as ctx:
-        ctx.set_options(precision="f64", bvh_builder=builder)
+        ctx.set_options(precision="f64", bvh_builder=builder, bvh_width=width)
         ctx.upload_scene(sc)
         ctx.set_sampler(seed)
         ctx.render_pass(0, 3, A.INTEGRATOR_MIS, 8, True)
         rgb, m = ctx.read_film()
         c = ctx.counters()
     rel = np.abs(rgb - ref).max(2) / np.maximum(np.abs(ref).max(2), 1e-3 * ref.mean())
-    print(builder, "closest", c.closest_rays, "shadow", c.shadow_rays, "occluded", c.shadow_occluded, "nan", c.nan_samples, "max rel", rel.max())
+    iy, ix = np.unravel_index(np.argmax(rel), rel.shape)
+    print("worst pixel", (ix, iy), "gpu", rgb[iy, ix], "restatement", ref[iy, ix])
+    print(builder, width, "closest", c.closest_rays, "shadow", c.shadow_rays, "occluded", c.shadow_occluded, "nan", c.nan_samples, "max rel", rel.max())
