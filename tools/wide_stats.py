@@ -22,7 +22,7 @@ desc = sc.desc()
 def walk(width, rays):
     pk = np.zeros(len(rays), np.uint32)
     t = np.zeros(len(rays), np.float64)
-    st = np.zeros(6, np.uint64)
+    st = np.zeros(8, np.uint64)
     assert lib.wide_stats(C.byref(desc), width, len(rays), rays.ctypes.data, pk.ctypes.data, t.ctypes.data, st.ctypes.data) == 0
     return pk, t, st
 
@@ -47,6 +47,8 @@ for width in (4, 8):
     out[width] = (pk, t)
     print(f"{width}-wide: {int(st[4])} nodes, builder's worst-case stack {int(st[5])}, deepest seen {int(st[3])}; per ray: node steps {st[0] / n:.2f}, "
           f"child-box tests {st[1] / n:.2f}, primitive tests {st[2] / n:.2f}, 16-byte node requests {st[0] * (4 if width == 4 else 5) / n:.1f}")
+    if width == 4:
+        print(f"        node steps on the first 85 / 341 nodes in level order (what an LDS copy of the top of the tree would serve): {st[6] / st[0]:.3f} / {st[7] / st[0]:.3f}")
 same = out[4][0] == out[8][0]
 near = np.abs(out[4][1] - out[8][1]) <= 1e-9 * np.maximum(1.0, out[4][1])
 print(f"closest-hit ids equal on {same.mean():.6f} of the rays; of the others {int((~same & near).sum())} are ties in distance, {int((~same & ~near).sum())} are not")

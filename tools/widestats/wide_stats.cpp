@@ -114,6 +114,25 @@ namespace
             return tn <= tf * 1.0000005;
         }
 
+        // 4-wide: position of every node in level (breadth-first) order, the order an LDS copy of the top of the tree would
+        // hold (fc_host.cpp: treelet_first); steps on the first 85 / 341 nodes = levels 0..3 / 0..4 of a full tree
+        std::vector<uint32_t> level_rank;
+        uint64_t steps_top85 = 0, steps_top341 = 0;
+        void rank_levels()
+        {
+            level_rank.assign(F.nodes.size(), 0xFFFFFFFFu);
+            std::vector<uint32_t> order{0u};
+            for(size_t k = 0; k < order.size(); ++k)
+            {
+                level_rank[order[k]] = static_cast<uint32_t>(k);
+                for(int c = 0; c < 4; ++c)
+                {
+                    const uint32_t ch = F.nodes[order[k]].child[c];
+                    if(ch != INVALID_U32 && !child_is_leaf(ch)) order.push_back(ch);
+                }
+            }
+        }
+
         uint32_t walk4(const Ray& r, double& t_max)
         {
             uint32_t pk = INVALID_U32;
@@ -130,6 +149,11 @@ namespace
                 }
                 const Node4& N = F.nodes[cur];
                 steps += 1;
+                if(!level_rank.empty())
+                {
+                    steps_top85 += level_rank[cur] < 85u ? 1 : 0;
+                    steps_top341 += level_rank[cur] < 341u ? 1 : 0;
+                }
                 const float org[3]{N.ox, N.oy, N.oz};
                 const double step[3]{N.sx, N.sy, N.sz};
                 std::pair<double, uint32_t> hit[4];
@@ -200,13 +224,15 @@ namespace
     };
 }
 
-// stats: [0] node steps, [1] child-box tests, [2] primitive tests, [3] deepest stack, [4] nodes, [5] max_stack the builder states
+// stats: [0] node steps, [1] child-box tests, [2] primitive tests, [3] deepest stack, [4] nodes, [5] max_stack the builder states,
+// [6] / [7] 4-wide: node steps on the first 85 / 341 nodes in level order
 extern "C" int wide_stats(const fcgpu_scene_desc* scene, int width, uint64_t n, const fcgpu_ray* rays, uint32_t* pk_out, double* t_out, uint64_t* stats)
 {
     FlatScene F;
     std::string err;
     if(flatten_scene(*scene, F, err, nullptr, false, width) != FCGPU_OK) return -1;
     Walker W{F};
+    if(width != 8) W.rank_levels();
     for(uint64_t i = 0; i < n; ++i)
     {
         Ray r;
@@ -228,5 +254,6 @@ extern "C" int wide_stats(const fcgpu_scene_desc* scene, int width, uint64_t n, 
     stats[0] = W.steps, stats[1] = W.child_tests, stats[2] = W.prim_tests, stats[3] = W.max_stack;
     stats[4] = width == 8 ? F.nodes8.size() : F.nodes.size();
     stats[5] = F.max_stack;
+    stats[6] = W.steps_top85, stats[7] = W.steps_top341;
     return 0;
 }
