@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -167,6 +168,14 @@ namespace
                     double tn;
                     if(slab(org, step, ql, qh, r, t_max, tn)) hit[nh++] = {tn, N.child[c]};
                 }
+                static const bool partial = std::getenv("WIDESTATS_PARTIAL_ORDER") != nullptr;  // what-if: only the nearest child is found, the others keep slot order
+                if(partial)
+                {
+                    int best = 0;
+                    for(int k = 1; k < nh; ++k) if(hit[k].first < hit[best].first) best = k;
+                    if(nh > 0) std::swap(hit[best], hit[nh - 1]);
+                }
+                else
                 std::sort(hit, hit + nh, [](auto& a, auto& b) { return a.first > b.first; });  // far first: the nearest is popped first
                 for(int k = 0; k < nh; ++k) stack.push_back(hit[k].second);
             }
