@@ -185,6 +185,7 @@ namespace
         S.stack_spill = c->stack_spill;
         S.stack_spill_stride = static_cast<uint32_t>(c->grid) * 256u;
         S.stack_spill_cap = c->stack_spill_entries;
+        S.max_stack = c->flat.max_stack;
         S.node_count = static_cast<uint32_t>(c->flat.nodes.size());
         S.textured_materials = 0;
         for(const MaterialRec& m : c->flat.materials) S.textured_materials |= static_cast<uint32_t>(m.textured);
@@ -901,12 +902,15 @@ extern "C"
             // The kernels without spill code stop pushing once fewer than three free LDS entries are left (one test per
             // node step instead of one per push), which is exact only while the worst case is <= STACK_CAP - 2: any
             // deeper hierarchy, including the ones that would just fit, runs the SPILL instantiations.
-            if(width == 4 && c->flat.max_stack > static_cast<uint32_t>(STACK_CAP - 2))
+            // The fp32 shadow kernel keeps SHADOW_STACK_CAP <= STACK_CAP entries in LDS (fc_types.h), so the columns are
+            // allocated and sized for it; which kernels run their SPILL instantiation is decided per kernel from
+            // SceneDev::max_stack (fc_kernels.hip: launch_*).
+            if(width == 4 && c->flat.max_stack > static_cast<uint32_t>(SHADOW_STACK_CAP - 2))
             {
                 // deep BVH: the part of the worst-case stack beyond the LDS entries lives in global memory,
                 // one column per lane of the persistent grid (and per batch slot)
                 void* p = nullptr;
-                const size_t entries = c->flat.max_stack > static_cast<uint32_t>(STACK_CAP) ? c->flat.max_stack - static_cast<uint32_t>(STACK_CAP) : 1u;
+                const size_t entries = c->flat.max_stack > static_cast<uint32_t>(SHADOW_STACK_CAP) ? c->flat.max_stack - static_cast<uint32_t>(SHADOW_STACK_CAP) : 1u;
                 c->stack_spill_entries = static_cast<uint32_t>(entries);
                 c->stack_spill_words = entries * static_cast<size_t>(c->grid) * 256u;
                 HIP_TRY(c, hipMalloc(&p, c->stack_spill_words * sizeof(uint32_t) * static_cast<size_t>(c->slots)));
@@ -1014,7 +1018,7 @@ extern "C"
         if(n == 0) return FCGPU_OK;
         if(!rays_dev || !hits_dev) return fail(c, FCGPU_E_INVALID, "null buffer");
         if(n > FCGPU_NOALLOC_MAX_RAYS) return fail(c, FCGPU_E_LIMIT, "fcgpu_trace_closest_noalloc: more than FCGPU_NOALLOC_MAX_RAYS (2^30) rays in one call");
-        const bool deep = c->stack_spill != nullptr;  // the scene runs the SPILL instantiations (set at upload)
+        const bool deep = c->flat.max_stack > static_cast<uint32_t>(STACK_CAP - 2);  // k_trace runs its SPILL instantiation (fc_kernels.hip: spills())
         if(c->flat.max_stack > static_cast<uint32_t>(STACK_CAP) + NOALLOC_SPILL_ENTRIES)
             return fail(c, FCGPU_E_LIMIT, "fcgpu_trace_closest_noalloc: the hierarchy needs more than FCGPU_NOALLOC_MAX_STACK (62) traversal-stack entries; use fcgpu_trace_closest_device");
         if(!c->noalloc_scratch) return fail(c, FCGPU_E_HIP, "no scratch address for this device");

@@ -368,6 +368,12 @@ namespace fcg
 #ifndef FCG_SHADOW_SPEC
 #define FCG_SHADOW_SPEC 0
 #endif
+#ifndef FCG_SHADOW_DENSE
+#define FCG_SHADOW_DENSE 1  // 0: the fp32 shadow rays run k_shadow<float, ...> with STACK_CAP entries like every other traversal kernel (A/B)
+#endif
+#ifndef FCG_SHADOW_DENSE_WAVES
+#define FCG_SHADOW_DENSE_WAVES 7  // waves per SIMD k_shadow_dense is compiled for (with FCG_SHADOW_STACK_CAP 22: seven blocks per CU)
+#endif
 #ifdef FCG_SHADOW_WAVES
 #define FCG_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(FCG_SHADOW_WAVES, FCG_SHADOW_WAVES)))
 #else
@@ -1149,11 +1155,10 @@ namespace fcg
     }
 
     // ------------------------------------------------------------------ shadow
-    template<typename R, bool SPILL, bool WIDE8 = false>
-    __global__ __launch_bounds__(BLOCK) FCG_SHADOW_ATTR void k_shadow(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    // CAP: entries of a lane's stack column in `stack_lds`
+    template<typename R, bool SPILL, bool WIDE8, int CAP>
+    FC_D void shadow_body(const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B, uint32_t* stack_lds, unsigned char* nodebuf_lds)
     {
-        __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
-        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[FCG_TREELET ? FCG_TREELET * 64 : WAVES * NODEBUF_WAVE];
         uint32_t* stack = stack_lds + threadIdx.x;
         unsigned char* nodebuf = FCG_TREELET ? nodebuf_lds : nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
         treelet_fill(S, nodebuf_lds);
@@ -1203,7 +1208,7 @@ namespace fcg
             if constexpr(WIDE8)
                 trav_round8<R, true, BLOCK>(S, T, stack, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
             else
-                trav_round<R, true, BLOCK, SPILL, false, FCG_SHADOW_SPEC != 0>(S, T, stack, nodebuf, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
+                trav_round<R, true, BLOCK, SPILL, false, FCG_SHADOW_SPEC != 0, CAP>(S, T, stack, nodebuf, n_overflow, B.descend_min_shadow, n_nodes, n_prims);
         }
         wave_stat_add(Q.stats, ST_SHADOW, n_cast);
         wave_stat_add(Q.stats, ST_OCCLUDED, n_occ);
@@ -1212,6 +1217,26 @@ namespace fcg
         wave_stat_add_uniform(Q.stats, ST_NODES, n_nodes);
         wave_stat_add(Q.stats, ST_PRIMS, n_prims);
     }
+
+    template<typename R, bool SPILL, bool WIDE8 = false>
+    __global__ __launch_bounds__(BLOCK) FCG_SHADOW_ATTR void k_shadow(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    {
+        __shared__ uint32_t stack_lds[STACK_CAP * BLOCK];
+        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[FCG_TREELET ? FCG_TREELET * 64 : WAVES * NODEBUF_WAVE];
+        shadow_body<R, SPILL, WIDE8, STACK_CAP>(S, Q, B, stack_lds, nodebuf_lds);
+    }
+
+#if !defined(FCG_ONLY_F64) && FCG_SHADOW_DENSE
+    // The product path's shadow kernel (fp32, 4-wide hierarchy): SHADOW_STACK_CAP entries in LDS and the registers of seven
+    // waves per SIMD (fc_types.h). Same code, same results.
+    template<bool SPILL>
+    __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FCG_SHADOW_DENSE_WAVES))) void k_shadow_dense(SceneDev<float> S, Wavefront<float> Q, Batch B)
+    {
+        __shared__ uint32_t stack_lds[SHADOW_STACK_CAP * BLOCK];
+        __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[FCG_TREELET ? FCG_TREELET * 64 : WAVES * NODEBUF_WAVE];
+        shadow_body<float, SPILL, false, SHADOW_STACK_CAP>(S, Q, B, stack_lds, nodebuf_lds);
+    }
+#endif
 
     // ------------------------------------------------------------------ accumulate
     // One thread per pixel of the batch, looping over the batch's samples: one writer per pixel,
@@ -1291,7 +1316,7 @@ namespace fcg
         __shared__ __attribute__((aligned(16))) unsigned char nodebuf_lds[FCG_TREELET ? FCG_TREELET * 64 : WAVES * NODEBUF_WAVE];
         unsigned char* nodebuf = FCG_TREELET ? nodebuf_lds : nodebuf_lds + (threadIdx.x >> 6) * NODEBUF_WAVE;
         treelet_fill(S, nodebuf_lds);
-        StackStats n_overflow;
+        StackStats n_overflow, dense_spill, dense_plain;
         // block-uniform trip count: every lane of a wave takes part in the cooperative node fetches
         for(uint64_t base = static_cast<uint64_t>(blockIdx.x) * BLOCK; base < n; base += static_cast<uint64_t>(gridDim.x) * BLOCK)
         {
@@ -1333,6 +1358,17 @@ namespace fcg
                 bool hit;
                 if constexpr(WIDE8)
                     hit = traverse8<R, true>(S, active, rc.o, rc.d, R(r.t_max), stack + threadIdx.x, t, pk, b0, b1, n_overflow);
+#if FCG_SHADOW_DENSE
+                else if constexpr(sizeof(R) == 4)
+                {
+                    // occlusion rays of the fp32 path use the LDS stack the way k_shadow_dense does (SHADOW_STACK_CAP entries,
+                    // the rest in the spill columns), so that fcgpu_trace_any tests that kernel's traversal
+                    if(S.stack_spill && S.max_stack > static_cast<uint32_t>(SHADOW_STACK_CAP - 2))
+                        hit = traverse<R, true, BLOCK, true, SHADOW_STACK_CAP>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, dense_spill);
+                    else
+                        hit = traverse<R, true, BLOCK, false, SHADOW_STACK_CAP>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, dense_plain);
+                }
+#endif
                 else
                     hit = traverse<R, true, BLOCK, SPILL>(S, active, rc, R(r.t_max), stack + threadIdx.x, nodebuf, t, pk, b0, b1, n_overflow);
                 if(active) occluded[i] = hit ? 1 : 0;
@@ -1340,6 +1376,10 @@ namespace fcg
         }
         if(SPILL) wave_stat_add(stats, ST_STACK_OVERFLOW, n_overflow.lost); else wave_stat_add_uniform(stats, ST_STACK_OVERFLOW, n_overflow.lost);
         wave_stat_add(stats, ST_STACK_SPILL, n_overflow.spilled);
+        // the fp32 occlusion rays' own counts (per lane with spill code, per wave without: StackStats)
+        wave_stat_add(stats, ST_STACK_OVERFLOW, dense_spill.lost);
+        wave_stat_add(stats, ST_STACK_SPILL, dense_spill.spilled);
+        wave_stat_add_uniform(stats, ST_STACK_OVERFLOW, dense_plain.lost);
     }
 
     // ------------------------------------------------------------------ scratch of fcgpu_trace_closest_noalloc
@@ -1483,6 +1523,8 @@ namespace fcg
     {
         hipLaunchKernelGGL(k_generate<R>, dim3(L.streaming()), dim3(BLOCK), 0, L.stream, S, Q, B);
     }
+    // the kernels with STACK_CAP entries in LDS run their SPILL instantiation (fc_api.cpp: upload allocates the columns)
+    template<typename R> static bool spills(const SceneDev<R>& S) { return S.stack_spill && S.max_stack > static_cast<uint32_t>(STACK_CAP - 2); }
     template<typename R> void launch_extend(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
         // SPILL variants only for scenes whose BVH needs more stack than the LDS holds (S.stack_spill set at upload),
@@ -1497,12 +1539,12 @@ namespace fcg
         }
         else if(S.textured_materials)
         {
-            if(S.stack_spill)
+            if(spills(S))
                 hipLaunchKernelGGL((k_extend<R, false, true, true>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
             else
                 hipLaunchKernelGGL((k_extend<R, false, false, true>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
         }
-        else if(S.stack_spill)
+        else if(spills(S))
             hipLaunchKernelGGL((k_extend<R, false, true, false>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
         else if(Q.timeline)
             hipLaunchKernelGGL((k_extend<R, true, false, false>), g, b, L.lds_pad_extend, L.stream, S, Q, B);
@@ -1543,8 +1585,21 @@ namespace fcg
     template<typename R> void launch_shadow(const LaunchCfg& L, const SceneDev<R>& S, const Wavefront<R>& Q, const Batch& B)
     {
         if(S.nodes8)
+        {
             hipLaunchKernelGGL((k_shadow<R, false, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
-        else if(S.stack_spill)
+            return;
+        }
+#if !defined(FCG_ONLY_F64) && FCG_SHADOW_DENSE
+        if constexpr(sizeof(R) == 4)
+        {
+            if(S.stack_spill && S.max_stack > static_cast<uint32_t>(SHADOW_STACK_CAP - 2))
+                hipLaunchKernelGGL((k_shadow_dense<true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
+            else
+                hipLaunchKernelGGL((k_shadow_dense<false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
+            return;
+        }
+#endif
+        if(spills(S))
             hipLaunchKernelGGL((k_shadow<R, true>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
         else
             hipLaunchKernelGGL((k_shadow<R, false>), dim3(L.grid), dim3(BLOCK), L.lds_pad_shadow, L.stream, S, Q, B);
@@ -1564,7 +1619,7 @@ namespace fcg
     {
         if(S.nodes8)
             hipLaunchKernelGGL((k_trace<R, false, true>), dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);
-        else if(S.stack_spill)
+        else if(spills(S))
             hipLaunchKernelGGL((k_trace<R, true>), dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);
         else
             hipLaunchKernelGGL((k_trace<R, false>), dim3(L.grid), dim3(BLOCK), 0, L.stream, S, n, rays, hits, occluded, stats);

@@ -212,7 +212,10 @@ namespace fcg
     // are not taken (far ones first) and returns the nearest one (or INVALID_U32 when none is hit).
     // The near / far plane of every axis is picked by the sign of the ray direction (rc.neg*), which
     // is what min/max of the two plane distances would give.
-    template<typename R, bool ANY, int STRIDE, bool SPILL>
+    // this lane's column of the global spill area, computed where it is used (rarely) instead of living in two registers
+    FC_D size_t spill_column() { return static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; }
+    // CAP: entries of the lane's LDS stack column (STACK_CAP, or the shorter one of the dense shadow kernel)
+    template<typename R, bool ANY, int STRIDE, bool SPILL, int CAP = STACK_CAP>
     FC_D uint32_t node_step(const RayCtx<R>& rc, R t_max, uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint32_t* stack, uint32_t* spill,
                             uint32_t spill_stride, int spill_cap, int& sp, StackStats& overflow, bool& lost_push)
     {
@@ -235,7 +238,7 @@ namespace fcg
             // in slot order, the first one to descend into and the others pushed: no keys, no sorting network (113 instead of
             // 132 VALU instructions per step, k_shadow -3 %). `room`: as below, one test per step; a SPILL kernel whose LDS
             // part is nearly full takes the general path below instead.
-            const bool room = sp <= STACK_CAP - 3;
+            const bool room = sp <= CAP - 3;
             if(!SPILL || room)
             {
                 uint32_t next = INVALID_U32;
@@ -273,11 +276,11 @@ namespace fcg
         if(!SPILL)
         {
             // one test per step instead of one per push: exact while the BVH's worst case is <= STACK_CAP - 2 entries (a step
-            // that has anything to push then starts at sp <= STACK_CAP - 3); the upload gives every deeper hierarchy,
+            // that has anything to push then starts at sp <= CAP - 3); the upload gives every deeper hierarchy,
             // also one that would just fit, the SPILL instantiation, so `room` is always true here
             // a lost push (cannot happen, see above) is reported as a predicate: the caller counts it per wave on the
             // scalar unit (the ballot of a comparison is its mask), which costs the vector unit nothing
-            const bool room = sp <= STACK_CAP - 3;
+            const bool room = sp <= CAP - 3;
             lost_push = !room && key[1] != INVALID_U32;
 #pragma unroll
             for(int k = 3; k >= 1; --k)
@@ -291,7 +294,7 @@ namespace fcg
         {
             // deep tree: entries beyond STACK_CAP go to this lane's column of the spill buffer; while three entries are free
             // in LDS (nearly always: the worst case is a bound over all rays) the pushes are those of the plain kernel
-            if(sp <= STACK_CAP - 3)
+            if(sp <= CAP - 3)
             {
 #pragma unroll
                 for(int k = 3; k >= 1; --k)
@@ -307,26 +310,26 @@ namespace fcg
             {
                 if(key[k] != INVALID_U32)
                 {
-                    if(sp < STACK_CAP)
+                    if(sp < CAP)
                         stack[sp * STRIDE] = ch[k];
-                    else if(sp < STACK_CAP + spill_cap)  // spill_cap: entries of the column actually supplied (SceneDev::stack_spill_cap)
+                    else if(sp < CAP + spill_cap)  // spill_cap: entries of the column actually supplied (SceneDev::stack_spill_cap)
                     {
-                        spill[static_cast<size_t>(sp - STACK_CAP) * spill_stride] = ch[k];
+                        spill[static_cast<size_t>(sp - CAP) * spill_stride + spill_column()] = ch[k];
                         overflow.spilled += 1;
                     }
                     else
                         overflow.lost += 1;
-                    sp += sp < STACK_CAP + spill_cap ? 1 : 0;
+                    sp += sp < CAP + spill_cap ? 1 : 0;
                 }
             }
         }
         return next;
     }
 
-    template<int STRIDE, bool SPILL> FC_D uint32_t stack_pop(const uint32_t* stack, const uint32_t* spill, uint32_t spill_stride, int& sp)
+    template<int STRIDE, bool SPILL, int CAP = STACK_CAP> FC_D uint32_t stack_pop(const uint32_t* stack, const uint32_t* spill, uint32_t spill_stride, int& sp)
     {
         sp -= 1;
-        if(SPILL && sp >= STACK_CAP) return spill[static_cast<size_t>(sp - STACK_CAP) * spill_stride];
+        if(SPILL && sp >= CAP) return spill[static_cast<size_t>(sp - CAP) * spill_stride + spill_column()];
         return stack[sp * STRIDE];
     }
 
@@ -419,13 +422,13 @@ namespace fcg
     // SPEC (speculative descent, after Aila & Laine 2009): a lane that reaches a leaf parks it in T.post and goes on with the
     // next entry of its stack instead of idling until the wave's leaf phase; it waits only once it holds a second leaf (or its
     // stack is empty). The primitives tested are the same for an ANY ray that is not occluded (nothing shrinks its t_max).
-    template<typename R, bool ANY, int STRIDE, bool SPILL, bool PROF = false, bool SPEC = false>
+    template<typename R, bool ANY, int STRIDE, bool SPILL, bool PROF = false, bool SPEC = false, int CAP = STACK_CAP>
     FC_D void trav_round(const SceneDev<R>& S, Trav<R>& T, uint32_t* stack, unsigned char* nodebuf, StackStats& overflow, int descend_min,
                          uint32_t& n_nodes, uint32_t& n_prims, unsigned long long* ph = nullptr)
     {
         unsigned long long c0 = 0;
         if(PROF) c0 = clock64();
-        uint32_t* spill = SPILL ? S.stack_spill + (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) : nullptr;
+        uint32_t* spill = SPILL ? S.stack_spill : nullptr;  // uniform: a lane's column is added where an entry is touched (spill_column)
         uint32_t cur = T.cur;
         uint32_t post = SPEC ? T.post : INVALID_U32;
         int sp = T.sp;
@@ -466,7 +469,7 @@ namespace fcg
                 }
                 np = nq;
 #endif
-                uint32_t next = node_step<R, ANY, STRIDE, SPILL>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, static_cast<int>(S.stack_spill_cap), sp, overflow, lost_push);
+                uint32_t next = node_step<R, ANY, STRIDE, SPILL, CAP>(T.rc, T.t_max, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, static_cast<int>(S.stack_spill_cap), sp, overflow, lost_push);
                 if(PROF) n_nodes += 1;  // per lane (the timeline wants the lane maximum); otherwise per wave, below
                 if(PROF && next == INVALID_U32)
                 {
@@ -476,11 +479,11 @@ namespace fcg
                     int sp2 = sp;
                     StackStats dummy;
                     bool dummy_lost = false;
-                    if(!SPILL && sp <= STACK_CAP - 3 &&
-                       node_step<R, ANY, STRIDE, SPILL>(T.rc, consts<R>::inf, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, static_cast<int>(S.stack_spill_cap), sp2, dummy, dummy_lost) != INVALID_U32)
+                    if(!SPILL && sp <= CAP - 3 &&
+                       node_step<R, ANY, STRIDE, SPILL, CAP>(T.rc, consts<R>::inf, np[0], np[1], np[2], np[3], stack, spill, S.stack_spill_stride, static_cast<int>(S.stack_spill_cap), sp2, dummy, dummy_lost) != INVALID_U32)
                         ph[12] += 1;
                 }
-                if(next == INVALID_U32 && sp > 0) next = stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp);
+                if(next == INVALID_U32 && sp > 0) next = stack_pop<STRIDE, SPILL, CAP>(stack, spill, S.stack_spill_stride, sp);
                 cur = next;
             }
             if(!PROF) n_nodes += __popcll(dm);  // node steps of the whole wave, counted on the scalar unit
@@ -490,7 +493,7 @@ namespace fcg
                 if(post == INVALID_U32 && child_is_leaf(cur) && cur != INVALID_U32)
                 {
                     post = cur;
-                    cur = sp > 0 ? stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
+                    cur = sp > 0 ? stack_pop<STRIDE, SPILL, CAP>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
                 }
                 leaf_waiting = leaf_waiting || __ballot(post != INVALID_U32) != 0ull;
             }
@@ -558,11 +561,11 @@ namespace fcg
                 else if(child_is_leaf(cur) && cur != INVALID_U32)
                 {
                     post = cur;
-                    cur = sp > 0 ? stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
+                    cur = sp > 0 ? stack_pop<STRIDE, SPILL, CAP>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
                 }
             }
             else
-                cur = (!stop && sp > 0) ? stack_pop<STRIDE, SPILL>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
+                cur = (!stop && sp > 0) ? stack_pop<STRIDE, SPILL, CAP>(stack, spill, S.stack_spill_stride, sp) : INVALID_U32;
         }
         T.cur = cur;
         if(SPEC) T.post = post;
@@ -799,7 +802,7 @@ namespace fcg
 
     // Whole-wave convenience wrapper (parity hooks): runs rounds until every ray of the wave is finished.
     // Lanes without a ray pass active = false (they still take part in the cooperative fetches).
-    template<typename R, bool ANY, int STRIDE, bool SPILL>
+    template<typename R, bool ANY, int STRIDE, bool SPILL, int CAP = STACK_CAP>
     FC_D bool traverse(const SceneDev<R>& S, bool active, const RayCtx<R>& rc, R t_max, uint32_t* stack, unsigned char* nodebuf, R& t_out,
                        uint32_t& pk_out, R& b0_out, R& b1_out, StackStats& overflow)
     {
@@ -813,7 +816,7 @@ namespace fcg
         T.post = INVALID_U32;
         T.sp = 0;
         uint32_t nn = 0, np = 0;
-        while(__ballot(!trav_done(T)) != 0ull) trav_round<R, ANY, STRIDE, SPILL>(S, T, stack, nodebuf, overflow, 12, nn, np);
+        while(__ballot(!trav_done(T)) != 0ull) trav_round<R, ANY, STRIDE, SPILL, false, false, CAP>(S, T, stack, nodebuf, overflow, 12, nn, np);
         t_out = T.t_max;
         pk_out = T.pk;
         b0_out = T.b0;

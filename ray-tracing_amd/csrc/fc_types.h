@@ -37,6 +37,15 @@ namespace fcg
 #define FCG_STACK_CAP 30
 #endif
     constexpr int STACK_CAP = FCG_STACK_CAP;
+    // The fp32 4-wide shadow kernel keeps a shorter column in LDS and fits 72 registers: 22 entries x 256 lanes x 4 B = 22 KB per
+    // block, seven blocks per CU = seven waves per SIMD instead of five (k_shadow -4 %). No ray of the bench scene goes deeper
+    // than 7 entries; hierarchies whose worst case exceeds SHADOW_STACK_CAP - 2 run its SPILL instantiation, whose entries
+    // beyond the LDS part live in the same global columns as k_extend's.
+#ifndef FCG_SHADOW_STACK_CAP
+#define FCG_SHADOW_STACK_CAP 22
+#endif
+    constexpr int SHADOW_STACK_CAP = FCG_SHADOW_STACK_CAP;
+    static_assert(SHADOW_STACK_CAP <= STACK_CAP, "the spill columns are sized for the shorter of the two LDS stacks");
     // entries beyond STACK_CAP spill to a per-lane column in global memory (allocated only for scenes
     // whose worst case needs them): deep trees work, shallow ones pay nothing
     constexpr int STACK_SPILL_MAX = 226;  // LDS traversal stack entries per lane: 30 KB per 256-thread block, 5 blocks per CU
@@ -269,10 +278,11 @@ namespace fcg
         const LightRec<R>* lights;
         const double* light_cdf;
         const TriShade<R>* tri_shade;  // by triangle index
-        uint32_t* stack_spill;     // [depth - STACK_CAP][grid lanes] or nullptr when the BVH fits the LDS stack
+        uint32_t* stack_spill;     // [depth - LDS entries of the kernel][grid lanes] or nullptr when the BVH fits every kernel's LDS stack
         uint32_t stack_spill_stride;
         uint32_t node_count;       // wide nodes
-        uint32_t stack_spill_cap;  // entries per lane column of stack_spill: pushes beyond STACK_CAP + this are counted as lost
+        uint32_t stack_spill_cap;  // entries per lane column of stack_spill: pushes beyond a kernel's LDS entries + this are counted as lost
+        uint32_t max_stack;        // worst-case traversal stack of the hierarchy: selects the SPILL instantiations per kernel
         uint32_t textured_materials;  // 1 = some material has image textures (selects the TEX kernel instantiations)
         CameraRec<R> camera;
         uint32_t light_count;

@@ -55,7 +55,7 @@ def ribbon_scene(n, g=1.1):
     return sc
 
 
-def cards_scene(n, g=1.2):
+def cards_scene(n, g=1.2, mirror=False):
     """n right triangles ("cards") in the planes z = g^k, corner at (-g^k, -g^k), legs 1.5 g^k: every card's box
     contains the z axis, its triangle only covers x + y <= -g^k / 2. The SAH tree is a chain (the biggest card is
     peeled off at every level), and a ray up the z axis from the small end pierces every box and misses the triangles:
@@ -69,6 +69,10 @@ def cards_scene(n, g=1.2):
     pos[2:3 * n:3] = np.stack([-s, 0.5 * s, s], 1)
     S_, Z = 2.0 * s[-1], 2.0 * s[-1]
     pos[3 * n:] = [[-S_, -S_, Z], [S_, -S_, Z], [S_, S_, Z], [-S_, S_, Z]]
+    if mirror:
+        # the same chain reflected in x and y: the builder then puts the interior remainder of every node into the FIRST slot,
+        # so that rays which take their children in slot order (occlusion rays) pile the leaf children up as well
+        pos[:, :2] *= -1.0
     idx = np.concatenate([np.arange(3 * n, dtype=np.uint32), np.array([3 * n, 3 * n + 1, 3 * n + 2, 3 * n, 3 * n + 2, 3 * n + 3], np.uint32)])
     sc = S.Scene()
     sc.entity(sc.mesh(pos, idx), sc.diffuse((0.7, 0.7, 0.7)))
@@ -77,7 +81,7 @@ def cards_scene(n, g=1.2):
     return sc
 
 
-def cards_rays(n_rays, seed):
+def cards_rays(n_rays, seed, mirror=False):
     """Rays up the z axis (tilted by up to 1e-3 towards +x, +y: exactly axis-parallel rays meet fp32's clamp of 1 / d at
     coordinates of 1e9) from just below the smallest card, at random (x, y) in [-0.9, 0.9]^2: those with x + y below
     -0.5 hit the first cards, the others miss every card and end on the backstop after filling the stack."""
@@ -88,6 +92,9 @@ def cards_rays(n_rays, seed):
     d = np.concatenate([1e-3 * rng.uniform(0, 1, (n_rays, 2)), np.ones((n_rays, 1))], 1)
     rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
     rays["t_max"] = np.inf
+    if mirror:
+        rays["origin"][:, :2] *= -1.0
+        rays["direction"][:, :2] *= -1.0
     return rays
 
 

@@ -8,3 +8,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def torch_sees_the_gpu_before_the_library_does():
+    """One GPU test (test_batch_size_is_halved...) fills the card through torch. torch ships its own HIP runtime, and on
+    this image it finds "No HIP GPUs" when it is initialised AFTER libfcgpu.so's runtime has opened the device in the same
+    process (the other order works). Running that test's file alone hit exactly that, so the order is fixed here, once
+    per session, instead of depending on which test file happens to run first. No GPU: nothing to do."""
+    try:
+        import torch
+    except ImportError:
+        return
+    if torch.cuda.is_available():
+        torch.cuda.init()

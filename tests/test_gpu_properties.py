@@ -351,6 +351,38 @@ def test_bvh_whose_stack_need_is_at_the_lds_capacity(n, depth):
         assert occ.all()
 
 
+@pytest.mark.parametrize("n,depth", [(50, 25), (58, 28), (72, 32)])
+def test_occlusion_rays_of_the_fp32_path_spill_beyond_their_shorter_lds_stack(n, depth):
+    """The fp32 shadow kernel keeps 22 entries per lane in LDS, not 30 (fc_types.h: SHADOW_STACK_CAP: seven waves per
+    SIMD), and fcgpu_trace_any runs its traversal: on hierarchies whose worst case lies between the two capacities (25, 28) only
+    the occlusion rays use the global spill columns, beyond 30 both kinds do; every answer equals the fp64 device's and the
+    CPU restatement's, no push is lost."""
+    from oracle import pyref
+
+    sc = cards_scene(n, mirror=True)  # the interior child in the first slot: rays that visit in slot order fill the stack too
+    rays = cards_rays(6000, n, mirror=True)
+    # besides the rays that pierce every box: rays that end between two cards (unoccluded) and rays that hit one
+    rays["t_max"][1::3] = np.random.default_rng(n).uniform(1.0, 1.2 ** (n - 1), len(rays[1::3]))
+    o = pyref.restatement("f64").scene(sc)
+    ref = o.trace_any(rays).astype(bool)
+    assert 0.2 < ref.mean() < 1.0
+    got = {}
+    for precision in ("f64", "f32"):
+        with R.GpuContext(0) as ctx:
+            ctx.set_options(precision=precision)
+            ctx.upload_scene(sc)
+            assert ctx.counters().reserved[1] == depth
+            ctx.reset_counters()
+            got[precision] = ctx.trace_any(rays).astype(bool)
+            c = ctx.counters()
+            assert c.stack_overflows == 0
+            # fp64: 30 entries in LDS; fp32 occlusion rays: 22
+            assert (int(c.reserved[5]) > 0) == (depth > (30 if precision == "f64" else 22)), (precision, int(c.reserved[5]))
+    assert np.array_equal(got["f64"], ref)
+    # fp32 decides grazing card edges and ray ends by rounding: a handful of rays may differ
+    assert (got["f32"] != ref).mean() < 2e-3
+
+
 def pixel_rel_err_max(a, b):
     from common import pixel_rel_err
     return float(pixel_rel_err(a, b).max())

@@ -19,8 +19,9 @@ for f in glob.glob(f"{out}/**/*counter_collection.csv", recursive=True):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         agg[k]["_dispatches_" + r["Counter_Name"]] += 1.0
 rays = json.load(open(f"{out}/rays.json")) if glob.glob(f"{out}/rays.json") else {}
-# the instantiations the bench workload runs: no profiling, no spill, no textures, 4-wide hierarchy
-names = {"k_extend<float, false, false, false, false>": ("k_extend", "closest_rays"), "k_shadow<float, false, false>": ("k_shadow", "shadow_rays"),
+# the instantiations the bench workload runs: no profiling, no spill, no textures, 4-wide hierarchy; the fp32 shadow rays run
+# k_shadow_dense (22 LDS stack entries; its SPILL instantiation on the room, whose worst case is 28)
+names = {"k_extend<float, false, false, false, false>": ("k_extend", "closest_rays"), "k_shadow_dense<true>": ("k_shadow", "shadow_rays"),
          "k_shade<float, 0, false>": ("k_shade_lambert", "closest_rays")}
 kern = {}
 for k, (short, unit) in names.items():

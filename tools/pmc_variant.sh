@@ -13,7 +13,7 @@ for v in default "$@"; do
   timeout -s KILL 170 rocprofv3 --output-format csv --pmc TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE -d $out/ta_$v -- python3 tools/gpu_perf.py 64 64 f32 > $out/ta_$v.log 2>&1
   python tools/prof_summary.py $out/ta_$v > $out/ta_$v.txt
   echo "== $v"
-  grep -h "k_extend<float\|k_shadow<float" $out/sq_$v.txt $out/ta_$v.txt | cut -c1-420
+  grep -h "k_extend<float\|k_shadow" $out/sq_$v.txt $out/ta_$v.txt | cut -c1-420
   grep -h "nodes/ray" $out/sq_$v.log || true
 done
 find $out -name "*.csv" -delete; find $out -name "*.db" -delete
