@@ -169,7 +169,10 @@ namespace
                     if(slab(org, step, ql, qh, r, t_max, tn)) hit[nh++] = {tn, N.child[c]};
                 }
                 static const bool partial = std::getenv("WIDESTATS_PARTIAL_ORDER") != nullptr;  // what-if: only the nearest child is found, the others keep slot order
-                if(partial)
+                static const bool slot_order = std::getenv("WIDESTATS_SLOT_ORDER") != nullptr;  // what-if: no ordering at all (first hit child in slot order is visited first)
+                if(slot_order)
+                    std::reverse(hit, hit + nh);
+                else if(partial)
                 {
                     int best = 0;
                     for(int k = 1; k < nh; ++k) if(hit[k].first < hit[best].first) best = k;
