@@ -379,10 +379,17 @@ namespace fcg
 #else
 #define FCG_SHADOW_ATTR
 #endif
+    // The spill-capable k_extend of untextured scenes (every hierarchy deeper than 28 entries) is held to the 96 registers of
+    // five waves per SIMD like the plain one (the compiler takes 106 = four waves otherwise; with the limit it spills 8 B per
+    // lane to scratch): k_extend -7.4 % on the room at tess 128. 0 = no limit (the textured instantiations, 120+ registers,
+    // lose more to scratch than a fifth wave gives them and are left alone).
+#ifndef FCG_EXTEND_SPILL_WAVES
+#define FCG_EXTEND_SPILL_WAVES 5
+#endif
 #ifdef FCG_EXTEND_WAVES
 #define FCG_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(FCG_EXTEND_WAVES, FCG_EXTEND_WAVES)))
 #else
-#define FCG_EXTEND_ATTR
+#define FCG_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(FCG_EXTEND_SPILL_WAVES && SPILL && !TEX && !PROF && !WIDE8 && sizeof(R) == 4 ? FCG_EXTEND_SPILL_WAVES : 1)))
 #endif
     template<typename R, bool PROF, bool SPILL, bool TEX, bool WIDE8 = false>
     __global__ __launch_bounds__(BLOCK) FCG_EXTEND_ATTR void k_extend(SceneDev<R> S, Wavefront<R> Q, Batch B)
