@@ -426,6 +426,15 @@ int fcgpu_trace_closest_noalloc(fcgpu_ctx* ctx, uint64_t n, const fcgpu_ray* ray
  * is the pixel value the reference writes. Synchronous.                                      */
 int fcgpu_clear_film(fcgpu_ctx* ctx);
 int fcgpu_read_film(fcgpu_ctx* ctx, double* rgb_sum, uint64_t* sample_count);
+/* Checkpoint / resume of a render between sample passes. The reference has no such thing (it writes its image once, at
+ * the end: renderer.hpp:115-141), but its film is resumable by construction -- running sums and a count
+ * (render_target.hpp:15-23, 45-47) -- and so is this one: fcgpu_save_film copies out the W*H*3 UNSCALED sums exactly as
+ * the device holds them (fcgpu_read_film's rgb_sum is these times W*H, a rounding that does not invert) and the sample
+ * count; fcgpu_restore_film puts both back into a context that holds a scene of the same resolution. A render that is
+ * saved after samples [0, k), restored into a fresh context and continued with [k, n) ends with the film of an
+ * uninterrupted render of [0, n), bit for bit (samples are added per pixel in index order either way). Synchronous.  */
+int fcgpu_save_film(fcgpu_ctx* ctx, double* raw_sum, uint64_t* sample_count);
+int fcgpu_restore_film(fcgpu_ctx* ctx, const double* raw_sum, uint64_t sample_count);
 /* Device view of the film (W*H*3 doubles, unscaled radiance sums: multiply by W*H to get the
  * reference's rgb_sum) and of the per-context sample counter, for in-place multi-GPU reduction
  * (the analogue of the per-worker film sum, renderer.hpp:129-133).                           */

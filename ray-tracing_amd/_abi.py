@@ -167,4 +167,5 @@ EXPORTS = [
     "fcgpu_film_device_ptr", "fcgpu_add_sample_count", "fcgpu_get_counters", "fcgpu_reset_counters",
     "fcgpu_sync", "fcgpu_set_profiling", "fcgpu_get_stage_times", "fcgpu_stream", "fcgpu_export_image", "fcgpu_version",
     "fcgpu_check_scene", "fcgpu_render_bands", "fcgpu_reduce_film", "fcgpu_bsdf_table", "fcgpu_trace_closest_noalloc", "fcgpu_set_decision_log", "fcgpu_read_decision_log", "fcgpu_device_count",
+    "fcgpu_save_film", "fcgpu_restore_film",
 ]

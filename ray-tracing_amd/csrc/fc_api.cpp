@@ -658,7 +658,7 @@ namespace
 
 extern "C"
 {
-    int fcgpu_version(void) { return 1004; }
+    int fcgpu_version(void) { return 1005; }
 
     int fcgpu_check_scene(const fcgpu_scene_desc* d, uint32_t bvh_builder, fcgpu_scene_stats* out)
     {
@@ -1307,6 +1307,37 @@ extern "C"
                 for(uint64_t i = 0; i < c->film_elems; ++i) rgb_sum[i] *= scale;
             }
             if(sample_count) *sample_count = c->samples;
+            return FCGPU_OK;
+        });
+    }
+
+    int fcgpu_save_film(fcgpu_ctx* c, double* raw_sum, uint64_t* sample_count)
+    {
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+            if(!raw_sum || !sample_count) return fail(c, FCGPU_E_INVALID, "null argument");
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpy(raw_sum, c->film, sizeof(double) * c->film_elems, hipMemcpyDeviceToHost));
+            *sample_count = c->samples;
+            return FCGPU_OK;
+        });
+    }
+
+    int fcgpu_restore_film(fcgpu_ctx* c, const double* raw_sum, uint64_t sample_count)
+    {
+        return guarded(c, [&]() -> int {
+            if(!c) return FCGPU_E_INVALID;
+            if(!c->has_scene) return fail(c, FCGPU_E_NOSCENE, "no scene uploaded");
+            if(!raw_sum) return fail(c, FCGPU_E_INVALID, "null argument");
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpy(c->film, raw_sum, sizeof(double) * c->film_elems, hipMemcpyHostToDevice));
+            // what the rows hold is no longer known to be one band pattern: a later fcgpu_reduce_film sends the whole frame
+            c->cover = fcgpu_ctx::Coverage{};
+            c->cover.any = true;
+            c->samples = sample_count;
             return FCGPU_OK;
         });
     }

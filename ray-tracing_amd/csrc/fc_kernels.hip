@@ -845,8 +845,13 @@ namespace fcg
     // ------------------------------------------------------------------ shade
     // KEY in [0, L_COUNT): a path arrives at a hit, then scatters with lobe type KEY.
     // KEY == Q_FINAL: the last vertex (path length == max_path_length): arrival terms only.
+#ifdef FCG_SHADE_WAVES  // experiment (tools/build_variant.sh): holds the untextured fp32 shade kernels to the registers of that many waves per SIMD
+#define FCG_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(!TEX && sizeof(R) == 4 ? FCG_SHADE_WAVES : 1)))
+#else
+#define FCG_SHADE_ATTR
+#endif
     template<typename R, int KEY, bool TEX>
-    __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev<R> S, Wavefront<R> Q, Batch B)
+    __global__ __launch_bounds__(BLOCK) FCG_SHADE_ATTR void k_shade(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
         __shared__ uint32_t q_lds[2][WAVES];
         __shared__ uint32_t* q_ctr[2];

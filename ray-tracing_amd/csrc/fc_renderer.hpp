@@ -7,6 +7,8 @@
 // Errors surface as std::runtime_error with the library's message (the C-ABI itself never throws).
 #pragma once
 #include <cstdint>
+#include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -58,6 +60,52 @@ namespace fcgpu
             verify();
         }
 
+        // Part of the job: samples [begin, begin + count) of every pixel. With save_checkpoint / load_checkpoint a render can
+        // stop between two such passes and go on later, in another process: the reference writes its image once, at the end
+        // (renderer.hpp:115-141), but its film is running sums + a count (render_target.hpp:15-23) and so is this one.
+        void run_samples(std::uint32_t begin, std::uint32_t count)
+        {
+            check(fcgpu_render_pass(ctx_, nullptr, begin, count, integrator_.kind, integrator_.max_path_length,
+                                    integrator_.visible_infinity_area_light ? 1 : 0));
+            check(fcgpu_sync(ctx_));
+            verify();
+        }
+
+        // `<path>`: 32-byte header {"FCFILM1", width, height, sample count, next sample index} + W*H*3 raw doubles
+        // (fcgpu_save_film: the sums as the device holds them, so that a resumed render is bit-identical to an uninterrupted one)
+        void save_checkpoint(const std::string& path, std::uint32_t next_sample)
+        {
+            std::vector<double> raw(3u * static_cast<std::size_t>(width_) * static_cast<std::size_t>(height_));
+            checkpoint_header h{};
+            std::memcpy(h.magic, "FCFILM1", 8);
+            h.width = static_cast<std::uint32_t>(width_);
+            h.height = static_cast<std::uint32_t>(height_);
+            h.next_sample = next_sample;
+            check(fcgpu_save_film(ctx_, raw.data(), &h.sample_count));
+            std::FILE* f = std::fopen(path.c_str(), "wb");
+            const bool ok = f && std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(raw.data(), sizeof(double), raw.size(), f) == raw.size();
+            if(f && std::fclose(f) != 0) throw std::runtime_error("gpu_renderer: cannot write " + path);
+            if(!ok) throw std::runtime_error("gpu_renderer: cannot write " + path);
+        }
+
+        // returns the index of the first sample that is still to render
+        std::uint32_t load_checkpoint(const std::string& path)
+        {
+            std::vector<double> raw(3u * static_cast<std::size_t>(width_) * static_cast<std::size_t>(height_));
+            checkpoint_header h{};
+            std::FILE* f = std::fopen(path.c_str(), "rb");
+            if(!f) throw std::runtime_error("gpu_renderer: cannot read " + path);
+            const bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "FCFILM1", 8) == 0 &&
+                            h.width == static_cast<std::uint32_t>(width_) && h.height == static_cast<std::uint32_t>(height_) &&
+                            std::fread(raw.data(), sizeof(double), raw.size(), f) == raw.size() && std::fgetc(f) == EOF;
+            std::fclose(f);
+            if(!ok) throw std::runtime_error("gpu_renderer: " + path + " is not a checkpoint of a " + std::to_string(width_) + "x" + std::to_string(height_) + " film");
+            check(fcgpu_restore_film(ctx_, raw.data(), h.sample_count));
+            return static_cast<std::uint32_t>(h.next_sample);
+        }
+
+        std::uint32_t sample_count() const { return sample_count_; }
+
         // a traversal-stack push that found no room means dropped BVH subtrees, i.e. a wrong image: the upload sizes the
         // stack so that this cannot happen, and a host must not ship the frame if it did
         void verify()
@@ -98,6 +146,14 @@ namespace fcgpu
         fcgpu_ctx* context() { return ctx_; }
 
     private:
+        struct checkpoint_header
+        {
+            char magic[8];
+            std::uint32_t width, height;
+            std::uint64_t sample_count, next_sample;
+        };
+        static_assert(sizeof(checkpoint_header) == 32, "checkpoint header layout");
+
         void check(int rc)
         {
             if(rc != FCGPU_OK) throw std::runtime_error(std::string("fcgpu error ") + std::to_string(rc) + ": " + fcgpu_last_error(ctx_));

@@ -55,6 +55,8 @@ def load_library():
         "fcgpu_read_decision_log": (i32, [vp, P(u32), P(u64), vp, vp]),
         "fcgpu_clear_film": (i32, [vp]),
         "fcgpu_read_film": (i32, [vp, vp, P(u64)]),
+        "fcgpu_save_film": (i32, [vp, vp, P(u64)]),
+        "fcgpu_restore_film": (i32, [vp, vp, u64]),
         "fcgpu_film_device_ptr": (i32, [vp, P(vp), P(u64)]),
         "fcgpu_add_sample_count": (i32, [vp, C.c_int64]),
         "fcgpu_get_counters": (i32, [vp, P(A.Counters)]),
@@ -223,6 +225,20 @@ class GpuContext:
         n = C.c_uint64(0)
         self._check(self.lib.fcgpu_read_film(self.h, rgb.ctypes.data, C.byref(n)))
         return rgb, n.value
+
+    def save_film(self):
+        """(raw_sum[H,W,3] float64 as the device holds it, sample_count): the checkpoint of a render between passes."""
+        raw = np.zeros((self.height, self.width, 3), np.float64)
+        n = C.c_uint64(0)
+        self._check(self.lib.fcgpu_save_film(self.h, raw.ctypes.data, C.byref(n)))
+        return raw, n.value
+
+    def restore_film(self, raw, sample_count):
+        """Puts a checkpoint (save_film) back: the next render_pass continues that render."""
+        raw = np.ascontiguousarray(raw, np.float64)
+        if raw.shape != (self.height, self.width, 3):
+            raise ValueError(f"checkpoint of shape {raw.shape} for a {self.width}x{self.height} film")
+        self._check(self.lib.fcgpu_restore_film(self.h, raw.ctypes.data, int(sample_count)))
 
     def film_device_view(self):
         """Object exposing __cuda_array_interface__ over the device film ([H, W, 3] float64, unscaled)."""

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(A.EXPORTS)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.fcgpu_version() == 1004
+    assert lib.fcgpu_version() == 1005
 
 
 def test_struct_layouts_match_header():

@@ -69,6 +69,38 @@ def test_sample_pass_split_sums():
     assert np.allclose(a + b, full, rtol=1e-13, atol=0)
 
 
+def test_checkpoint_and_resume_is_bit_exact():
+    """fcgpu_save_film / fcgpu_restore_film: a render saved after samples [0, 3), restored into a FRESH context and continued
+    with [3, 8) ends with the film of an uninterrupted render of [0, 8), bit for bit, in both precisions; the checkpoint is
+    the raw device sums (read_film's rgb_sum divided by W*H would not invert exactly); a checkpoint of another resolution
+    is refused by the host wrapper, a null pointer by the library."""
+    sc = S.room(width=160, height=90, tess=8)
+    for precision in ("f32", "f64"):
+        full, n, _ = render(sc, precision=precision, spp=8)
+        with R.GpuContext(0) as ctx:
+            ctx.set_options(precision=precision)
+            ctx.upload_scene(sc)
+            ctx.set_sampler(0)
+            ctx.render_pass(0, 3)
+            raw, k = ctx.save_film()
+            part, k2 = ctx.read_film()
+        assert k == k2 == 160 * 90 * 3
+        assert np.allclose(raw * (160.0 * 90.0), part, rtol=1e-15, atol=0)
+        with R.GpuContext(0) as ctx:
+            ctx.set_options(precision=precision)
+            ctx.upload_scene(sc)
+            ctx.set_sampler(0)
+            ctx.restore_film(raw, k)
+            ctx.render_pass(3, 5)
+            resumed, m = ctx.read_film()
+            assert ctx.counters().samples == n
+            with pytest.raises(ValueError):
+                ctx.restore_film(raw[:10], k)
+            assert ctx.lib.fcgpu_restore_film(ctx.h, None, 0) == A.E_INVALID
+            assert ctx.lib.fcgpu_save_film(ctx.h, None, None) == A.E_INVALID
+        assert m == n and np.array_equal(resumed, full)
+
+
 def test_emission_linearity():
     """Scaling every emitter by 2 scales the image by exactly 2 (power of two: exact in fp)."""
     sc1 = S.room(width=96, height=54, tess=4)
@@ -252,6 +284,13 @@ def test_cpp_host_renders_the_room_from_asset_files(tmp_path):
     img3 = np.fromfile(tmp_path / "room.raw", dtype=np.float32).reshape(h, w, 3)
     assert np.array_equal(img, img3)
     assert out.stdout.split("rays")[1].split()[0] == out3.stdout.split("rays")[1].split()[0]
+    # the same host stopped after 1 of its 4 samples per pixel, checkpointed to a file (gpu_renderer::save_checkpoint) and
+    # finished by a NEW renderer that loads it: the image an uninterrupted run writes, byte for byte
+    outc = subprocess.run([exe, str(w), str(h), str(spp), str(tmp_path), "1", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert outc.returncode == 0, outc.stdout + outc.stderr
+    assert os.path.getsize(tmp_path / "room.ckpt") == 32 + 24 * w * h
+    imgc = np.fromfile(tmp_path / "room.raw", dtype=np.float32).reshape(h, w, 3)
+    assert np.array_equal(img, imgc)
 
 
 def test_deep_bvh_spills_the_traversal_stack_and_still_matches_the_oracle():
