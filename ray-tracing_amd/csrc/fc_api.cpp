@@ -1376,6 +1376,18 @@ extern "C"
             out->bvh_nodes = c->flat.nodes8.empty() ? c->flat.nodes.size() : c->flat.nodes8.size();
             out->primitives = c->flat.prim_info.size();
             out->kernel_launches = c->launches;
+#ifdef FCG_SHADE_CLOCKS
+            {
+                static const char* names[8] = {"wait for the prefetched records", "surface point + entity", "arrival terms", "material + lobe record",
+                                               "light strategy", "bsdf strategy", "queue append", "next loads + stores issued"};
+                unsigned long long total = 0;
+                for(int k = 0; k < 8; ++k) total += st[ST_SHADE_PH0 + k];
+                if(total)
+                    for(int k = 0; k < 8; ++k)
+                        std::fprintf(stderr, "k_shade<Lambert> phase %d (%s): %.1f %% of the wave cycles, %.0f cycles per trip\n", k, names[k],
+                                     100.0 * st[ST_SHADE_PH0 + k] / total, double(st[ST_SHADE_PH0 + k]) / double(st[ST_SHADE_PH0 + 8] ? st[ST_SHADE_PH0 + 8] : 1));
+            }
+#endif
             out->reserved[0] = st[ST_MEDIUM_OVERFLOW];
             out->reserved[1] = c->flat.max_stack;
             out->reserved[2] = c->flat.binary_nodes;

@@ -845,14 +845,39 @@ namespace fcg
     // ------------------------------------------------------------------ shade
     // KEY in [0, L_COUNT): a path arrives at a hit, then scatters with lobe type KEY.
     // KEY == Q_FINAL: the last vertex (path length == max_path_length): arrival terms only.
-#ifdef FCG_SHADE_WAVES  // experiment (tools/build_variant.sh): holds the untextured fp32 shade kernels to the registers of that many waves per SIMD
-#define FCG_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(!TEX && sizeof(R) == 4 ? FCG_SHADE_WAVES : 1)))
+#ifndef FCG_SHADE_LIGHT_FIRST
+#define FCG_SHADE_LIGHT_FIRST 0  // 1: k_shade samples the emitter before it reconstructs the hit (A/B of DESIGN.md section 5)
+#endif
+#ifdef FCG_SHADE_WAVES  // experiment (tools/build_variant.sh): holds the untextured fp32 Lambert shade kernel to the registers of that many waves per SIMD
+#define FCG_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(!TEX && sizeof(R) == 4 && KEY == L_LAMBERT ? FCG_SHADE_WAVES : 1)))
 #else
 #define FCG_SHADE_ATTR
+#endif
+    // FCG_SHADE_CLOCKS (development build): wave cycles between marks of a k_shade<float, Lambert> trip, summed into the
+    // statistics words behind ST_SHADE_PH0 and printed by fcgpu_get_counters. A mark waits for the value named (or, WAIT = 1,
+    // for every outstanding memory operation) so that the time is booked where the wave really sat.
+#ifdef FCG_SHADE_CLOCKS
+#define SHADE_MARK(k, WAIT, value)                                                  \
+    do                                                                              \
+    {                                                                               \
+        if constexpr(KEY == L_LAMBERT && !TEX && sizeof(R) == 4)                    \
+        {                                                                           \
+            asm volatile("" ::"v"(value));                                          \
+            if(WAIT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+            const unsigned long long now_ = clock64();                              \
+            sc_ph[k] += now_ - sc_t;                                                \
+            sc_t = now_;                                                            \
+        }                                                                           \
+    } while(0)
+#else
+#define SHADE_MARK(k, WAIT, value)
 #endif
     template<typename R, int KEY, bool TEX>
     __global__ __launch_bounds__(BLOCK) FCG_SHADE_ATTR void k_shade(SceneDev<R> S, Wavefront<R> Q, Batch B)
     {
+#ifdef FCG_SHADE_CLOCKS
+        unsigned long long sc_ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sc_t = clock64();
+#endif
         __shared__ uint32_t q_lds[2][WAVES];
         __shared__ uint32_t* q_ctr[2];
         if(threadIdx.x == 0)
@@ -897,6 +922,7 @@ namespace fcg
             if(i < n)
             {
                 const Vec4<R> h0 = nx_h0, h1 = nx_h1;
+                SHADE_MARK(0, 0, nx_s2.z + nx_s1.z + nx_s0.z + nx_h0.z + nx_h1.x);
                 uint32_t hw, path;  // hw = hit_word(kind | index, lobe)
                 unpack_ids(h1, hw, path);
                 uint32_t ms = unpack_word(h1.y);
@@ -904,10 +930,37 @@ namespace fcg
                 vec3<R> beta{st.beta[0], st.beta[1], st.beta[2]};
                 const vec3<R> p1{st.p1[0], st.p1[1], st.p1[2]};
                 const vec3<R> w12{st.w[0], st.w[1], st.w[2]};  // direction that reached this hit
+#if FCG_SHADE_LIGHT_FIRST
+                // The light pick and the point on the emitter depend on the path's sample stream only, not on the hit: their
+                // chain of dependent gathers (light record -> CDF cells -> primitive -> triangle) is started here, so that it
+                // runs beside the hit's own chain (shading record -> entity -> material -> lobe) instead of after it.
+                // Same arithmetic, same results; the light strategy below uses what is prepared here.
+                constexpr bool LIGHT_FIRST = KEY != Q_FINAL && !(KEY == L_SPEC_REFL || KEY == L_SPEC_GLASS || KEY == L_SPEC_TRANS);
+                uint32_t lf_li = 0;
+                R lf_ux = R(0), lf_uy = R(0);
+                vec3<R> lf_pL{}, lf_nL{};
+                if constexpr(LIGHT_FIRST)
+                {
+                    if(mis && S.light_count > 0u)
+                    {
+                        const fcgpu_sample_stream lkey = slot_stream(B, path);
+                        const uint64_t bits = fcgpu_stream_bits(&B.sampler, lkey, dim + 1u);
+                        lf_li = static_cast<uint32_t>((static_cast<uint64_t>(fcgpu_sample_x24(bits)) * S.light_count) >> 24);
+                        if(lf_li >= S.light_count) lf_li = S.light_count - 1u;  // uniform_light_distribution.hpp:13-17
+                        draw(B, lkey, dim + 2u, lf_ux, lf_uy);
+                        if(!(S.env_kind != FCGPU_ENV_NONE && lf_li == S.light_count - 1u))
+                        {
+                            const uint64_t pbits = fcgpu_stream_bits(&B.sampler, lkey, dim + 3u);
+                            light_sample_point(S, S.lights[lf_li], fcgpu_sample_x24(pbits) * FCGPU_SAMPLER_SCALE, lf_ux, lf_uy, lf_pL, lf_nL);
+                        }
+                    }
+                }
+#endif
                 SurfacePoint<R> sp = make_surface_point(S, hit_word_kind(hw), hit_word_index(hw), vec3<R>{h0.x, h0.y, h0.z}, h0.w, h1.x);
                 const EntityRec ent = S.entities[sp.entity];
                 const vec3<R> ng = sp.f.ng;
                 const uint32_t above = ms_above(ms), below = ms_below(ms);
+                SHADE_MARK(1, 0, ent.material);
 
                 // ---- arrival at p2 = sp.p along w12 (forward_mis_integrator.hpp:128-147 / :181-196)
                 if(B.h > 1)
@@ -949,6 +1002,7 @@ namespace fcg
                     Q.li_shadow[path] = acc;
                 }
 
+                SHADE_MARK(2, 1, beta.x);
                 bool alive = false;
                 R pdf_w12 = R(0);
                 vec3<R> wn{};
@@ -982,18 +1036,24 @@ namespace fcg
                         L = S.lobes[mat.first_lobe + hit_word_lobe(hw)];
                     }
                     const R eta_a = S.media[above].ior, eta_b = S.media[below].ior;
+                    SHADE_MARK(3, 1, eta_a + eta_b);
                     const fcgpu_sample_stream key = slot_stream(B, path);
                     constexpr bool DELTA = KEY == L_SPEC_REFL || KEY == L_SPEC_GLASS || KEY == L_SPEC_TRANS;
 
                     if(!DELTA && mis && S.light_count > 0u)
                     {
                         // light strategy, :52-99
+#if FCG_SHADE_LIGHT_FIRST
+                        const uint32_t li = lf_li;
+                        const R ux = lf_ux, uy = lf_uy;
+#else
                         uint64_t bits = fcgpu_stream_bits(&B.sampler, key, dim + 1u);
                         uint32_t li = static_cast<uint32_t>((static_cast<uint64_t>(fcgpu_sample_x24(bits)) * S.light_count) >> 24);
                         if(li >= S.light_count) li = S.light_count - 1u;  // uniform_light_distribution.hpp:13-17
-                        R pdf_light = R(1) / R(S.light_count);
                         R ux, uy;
                         draw(B, key, dim + 2u, ux, uy);
+#endif
+                        R pdf_light = R(1) / R(S.light_count);
                         const bool is_env = S.env_kind != FCGPU_ENV_NONE && li == S.light_count - 1u;
                         if(is_env)
                         {
@@ -1022,10 +1082,14 @@ namespace fcg
                         {
                             // standard_light::sample_p, const_diffuse_area_light.hpp:28-42
                             const LightRec<R>& Lt = S.lights[li];
+#if FCG_SHADE_LIGHT_FIRST
+                            const vec3<R> pL = lf_pL, nL = lf_nL;
+#else
                             uint64_t pbits = fcgpu_stream_bits(&B.sampler, key, dim + 3u);
                             double u_prim = fcgpu_sample_x24(pbits) * FCGPU_SAMPLER_SCALE;
                             vec3<R> pL, nL;
                             light_sample_point(S, Lt, u_prim, ux, uy, pL, nL);
+#endif
                             vec3<R> LeL = dot(nL, sp.p - pL) > R(0) ? rgb(Lt.Le) : vec3<R>{R(0), R(0), R(0)};
                             vec3<R> d1L = pL - sp.p;
                             vec3<R> w1L = normalize(d1L);
@@ -1052,6 +1116,7 @@ namespace fcg
                         }
                     }
 
+                    SHADE_MARK(4, 1, s2.x + s0.x);
                     // BSDF strategy, :101-113 / :157-169 (u2 = first draw, u1 = second: right-to-left arguments)
                     R u1x, u1y, u2x, u2y;
                     draw(B, key, dim_u2, u2x, u2y);
@@ -1095,9 +1160,11 @@ namespace fcg
                     nst.ms_ext = pack_word(R(0), ms_ext_out);
                 }
             }
+            SHADE_MARK(5, 1, r0.x + nst.beta[0]);
             uint32_t slot_r = 0, slot_s = 0;
             // two independent appends share one pass: queue 0 = extension rays, queue 1 = shadow rays
             if constexpr(KEY != Q_FINAL) block_append2(emit_ray, emit_shadow, q_ctr, q_lds, slot_r, slot_s);
+            SHADE_MARK(6, 0, slot_r + slot_s);
             {
                 // the coming trip's records and the index of the one after it (see the top of the loop)
                 // unconditional (a trip past the end re-reads record 0 and drops it): a conditional request would keep
@@ -1125,7 +1192,16 @@ namespace fcg
                     st_stream(&Q.sh_c2[slot_s], s2);
                 }
             }
+            SHADE_MARK(7, 0, slot_r);
+#ifdef FCG_SHADE_CLOCKS
+            sc_ph[8] += 1;
+#endif
         }
+#ifdef FCG_SHADE_CLOCKS
+        if constexpr(KEY == L_LAMBERT && !TEX && sizeof(R) == 4)
+            if((threadIdx.x & 63) == 0)
+                for(int k = 0; k < 9; ++k) atomicAdd(&Q.stats[ST_SHADE_PH0 + k], sc_ph[k]);
+#endif
     }
 
     // paths that left the scene: environment term (forward_mis_integrator.hpp:29-35, 115-125, 171-178)

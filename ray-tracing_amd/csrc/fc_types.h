@@ -430,7 +430,12 @@ namespace fcg
 
     enum StatIndex
     {
-        ST_CLOSEST = 0, ST_SHADOW = 1, ST_OCCLUDED = 2, ST_NAN = 3, ST_STACK_OVERFLOW = 4, ST_MEDIUM_OVERFLOW = 5, ST_NODES = 6, ST_PRIMS = 7, ST_STACK_SPILL = 8, ST_MEDIUM_DEEP = 9, ST_COUNT = 10
+        ST_CLOSEST = 0, ST_SHADOW = 1, ST_OCCLUDED = 2, ST_NAN = 3, ST_STACK_OVERFLOW = 4, ST_MEDIUM_OVERFLOW = 5, ST_NODES = 6, ST_PRIMS = 7, ST_STACK_SPILL = 8, ST_MEDIUM_DEEP = 9,
+#ifdef FCG_SHADE_CLOCKS  // development build (tools/build_variant.sh): wave cycles per phase of a k_shade<Lambert> trip, [8] = trips
+        ST_SHADE_PH0 = 10, ST_COUNT = 20
+#else
+        ST_COUNT = 10
+#endif
     };
 
     template<typename R>
