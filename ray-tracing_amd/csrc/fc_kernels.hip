@@ -845,10 +845,24 @@ namespace fcg
     // ------------------------------------------------------------------ shade
     // KEY in [0, L_COUNT): a path arrives at a hit, then scatters with lobe type KEY.
     // KEY == Q_FINAL: the last vertex (path length == max_path_length): arrival terms only.
+    // Where in a trip k_shade requests the coming trip's records (software pipeline, see the kernel): 0 after the queue append,
+    // 1 before it, 2 before the BSDF strategy, 3 before the light strategy. 1 is the default: the five loads then fly during
+    // the append's three barriers and its returning atomic, with the same registers live as after it; measured against 0 on one
+    // box, five alternating pairs: k_shade 70.1 -> 67.6 ms per step (-3.5 %), films bit-identical. 2 and 3 keep 21 more
+    // registers live through the strategies and gain nothing.
+#ifndef FCG_SHADE_LOADS_AT
+#define FCG_SHADE_LOADS_AT 1
+#endif
 #ifndef FCG_SHADE_LIGHT_FIRST
 #define FCG_SHADE_LIGHT_FIRST 0  // 1: k_shade samples the emitter before it reconstructs the hit (A/B of DESIGN.md section 5)
 #endif
-#ifdef FCG_SHADE_WAVES  // experiment (tools/build_variant.sh): holds the untextured fp32 Lambert shade kernel to the registers of that many waves per SIMD
+    // The untextured fp32 Lambert instantiation (a quarter of the headline step) is held to the 128 registers of four waves per
+    // SIMD, where it sat by itself before the loads moved (the allocator takes 129 with them in front of the append; the limit
+    // costs no scratch beyond the 20 B every instantiation has). 0 = no limit.
+#ifndef FCG_SHADE_WAVES
+#define FCG_SHADE_WAVES 4
+#endif
+#if FCG_SHADE_WAVES
 #define FCG_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(!TEX && sizeof(R) == 4 && KEY == L_LAMBERT ? FCG_SHADE_WAVES : 1)))
 #else
 #define FCG_SHADE_ATTR
@@ -919,6 +933,19 @@ namespace fcg
             bool emit_ray = false, emit_shadow = false;
             Vec4<R> r0{}, r1{}, s0{}, s1{}, s2{};
             PathState<R> nst{};  // the state that travels on with the extension ray (written beside it, below)
+            // the coming trip's records and the index of the one after it (see the top of the loop); unconditional (a trip past
+            // the end re-reads record 0 and drops it): a conditional request would keep the old values alive through the whole
+            // trip. Where in the trip it is issued: FCG_SHADE_LOADS_AT.
+            auto request_next = [&]()
+            {
+                const uint64_t i2 = static_cast<uint64_t>(i) + stride + stride;
+                nx_h0 = ld_stream(&Q.hit_c0[hi_next]);
+                nx_h1 = ld_stream(&Q.hit_c1[hi_next]);
+                nx_s0 = ld_stream(&Q.st_c0[B.parity][hi_next]);
+                nx_s1 = ld_stream(&Q.st_c1[B.parity][hi_next]);
+                nx_s2 = ld_stream_xyz(&Q.st_c2[B.parity][hi_next]);
+                hi_next = hit_idx[i2 < n ? static_cast<uint32_t>(i2) : 0u];
+            };
             if(i < n)
             {
                 const Vec4<R> h0 = nx_h0, h1 = nx_h1;
@@ -1040,6 +1067,7 @@ namespace fcg
                     const fcgpu_sample_stream key = slot_stream(B, path);
                     constexpr bool DELTA = KEY == L_SPEC_REFL || KEY == L_SPEC_GLASS || KEY == L_SPEC_TRANS;
 
+                    if constexpr(FCG_SHADE_LOADS_AT == 3 && !DELTA) request_next();
                     if(!DELTA && mis && S.light_count > 0u)
                     {
                         // light strategy, :52-99
@@ -1117,6 +1145,7 @@ namespace fcg
                     }
 
                     SHADE_MARK(4, 1, s2.x + s0.x);
+                    if constexpr(FCG_SHADE_LOADS_AT == 2 && !DELTA) request_next();
                     // BSDF strategy, :101-113 / :157-169 (u2 = first draw, u1 = second: right-to-left arguments)
                     R u1x, u1y, u2x, u2y;
                     draw(B, key, dim_u2, u2x, u2y);
@@ -1160,23 +1189,15 @@ namespace fcg
                     nst.ms_ext = pack_word(R(0), ms_ext_out);
                 }
             }
+            if constexpr(FCG_SHADE_LOADS_AT >= 2 && KEY != Q_FINAL && !(KEY == L_SPEC_REFL || KEY == L_SPEC_GLASS || KEY == L_SPEC_TRANS))
+                if(i >= n) request_next();  // lanes without a hit in this (last) trip: their records are dropped either way
             SHADE_MARK(5, 1, r0.x + nst.beta[0]);
             uint32_t slot_r = 0, slot_s = 0;
+            if constexpr(FCG_SHADE_LOADS_AT == 1 || KEY == Q_FINAL || (FCG_SHADE_LOADS_AT >= 2 && (KEY == L_SPEC_REFL || KEY == L_SPEC_GLASS || KEY == L_SPEC_TRANS))) request_next();
             // two independent appends share one pass: queue 0 = extension rays, queue 1 = shadow rays
             if constexpr(KEY != Q_FINAL) block_append2(emit_ray, emit_shadow, q_ctr, q_lds, slot_r, slot_s);
             SHADE_MARK(6, 0, slot_r + slot_s);
-            {
-                // the coming trip's records and the index of the one after it (see the top of the loop)
-                // unconditional (a trip past the end re-reads record 0 and drops it): a conditional request would keep
-                // the old values alive through the whole trip
-                const uint64_t i2 = static_cast<uint64_t>(i) + stride + stride;
-                nx_h0 = ld_stream(&Q.hit_c0[hi_next]);
-                nx_h1 = ld_stream(&Q.hit_c1[hi_next]);
-                nx_s0 = ld_stream(&Q.st_c0[B.parity][hi_next]);
-                nx_s1 = ld_stream(&Q.st_c1[B.parity][hi_next]);
-                nx_s2 = ld_stream_xyz(&Q.st_c2[B.parity][hi_next]);
-                hi_next = hit_idx[i2 < n ? static_cast<uint32_t>(i2) : 0u];
-            }
+            if constexpr(FCG_SHADE_LOADS_AT == 0 && KEY != Q_FINAL) request_next();
             if constexpr(KEY != Q_FINAL)
             {
                 if(emit_ray)
