@@ -802,8 +802,12 @@ namespace fcg
             // confirm it (cdf[g] <= u < cdf[g + 1] holds for exactly that k); any other case takes the search.
             uint32_t tri = static_cast<uint32_t>(u * static_cast<double>(Lt.tri_count));
             if(tri >= Lt.tri_count) tri = Lt.tri_count - 1;
+            // One round trip for the three: both cells are requested before the first is compared (`&`, not `&&`: the
+            // short-circuit form made the second load wait for the first comparison), and the primitive of the guessed
+            // cell with them (used unless the search below picks another triangle).
             const double c0 = cdf[tri], c1 = cdf[tri + 1];
-            if(!(c0 <= u && c1 > u))
+            uint32_t record = S.prim_info[Lt.first_prim + tri].kind_index;
+            if(!(static_cast<int>(c0 <= u) & static_cast<int>(c1 > u)))
             {
                 uint32_t lo = 0, hi = Lt.tri_count + 1;  // upper_bound over cdf[0..tri_count]
                 while(lo < hi)
@@ -816,8 +820,9 @@ namespace fcg
                 }
                 tri = lo - 1;
                 if(tri >= Lt.tri_count) tri = Lt.tri_count - 1;
+                record = S.prim_info[Lt.first_prim + tri].kind_index;
             }
-            const TriRec& T = S.tris[S.prim_info[Lt.first_prim + tri].kind_index & 0x3FFFFFFFu];
+            const TriRec& T = S.tris[record & 0x3FFFFFFFu];
             vec3<R> p0 = ldv<R>(T.v0), p1 = ldv<R>(T.v1), p2 = ldv<R>(T.v2);
             R su0 = r_sqrt(ux);  // sample_triangle_uniform, sampling.hpp:62-66
             R bx = R(1) - su0, by = uy * su0;
@@ -858,12 +863,18 @@ namespace fcg
 #endif
     // The untextured fp32 Lambert instantiation (a quarter of the headline step) is held to the 128 registers of four waves per
     // SIMD, where it sat by itself before the loads moved (the allocator takes 129 with them in front of the append; the limit
-    // costs no scratch beyond the 20 B every instantiation has). 0 = no limit.
+    // costs no scratch beyond the 20 B every instantiation has), its textured twin to the 168 of three (167 before the light
+    // record was loaded by value, 169 after). 0 = no limit.
 #ifndef FCG_SHADE_WAVES
 #define FCG_SHADE_WAVES 4
 #endif
 #if FCG_SHADE_WAVES
-#define FCG_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(!TEX && sizeof(R) == 4 && KEY == L_LAMBERT ? FCG_SHADE_WAVES : 1)))
+    // (the textured microfacet-transmission instantiation sat at 168 too and is held there like the textured Lambert one)
+    constexpr int shade_waves(bool f32, int key, bool tex)
+    {
+        return !f32 ? 1 : key == L_LAMBERT ? (tex ? FCG_SHADE_WAVES - 1 : FCG_SHADE_WAVES) : (tex && key == L_GGX_TRANS ? FCG_SHADE_WAVES - 1 : 1);
+    }
+#define FCG_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(shade_waves(sizeof(R) == 4, KEY, TEX))))
 #else
 #define FCG_SHADE_ATTR
 #endif
@@ -978,7 +989,8 @@ namespace fcg
                         if(!(S.env_kind != FCGPU_ENV_NONE && lf_li == S.light_count - 1u))
                         {
                             const uint64_t pbits = fcgpu_stream_bits(&B.sampler, lkey, dim + 3u);
-                            light_sample_point(S, S.lights[lf_li], fcgpu_sample_x24(pbits) * FCGPU_SAMPLER_SCALE, lf_ux, lf_uy, lf_pL, lf_nL);
+                            const LightRec<R> lf_Lt = S.lights[lf_li];
+                            light_sample_point(S, lf_Lt, fcgpu_sample_x24(pbits) * FCGPU_SAMPLER_SCALE, lf_ux, lf_uy, lf_pL, lf_nL);
                         }
                     }
                 }
@@ -993,10 +1005,10 @@ namespace fcg
                 if(B.h > 1)
                 {
                     const bool entering = dot(ng, w12) <= R(0);
-                    const MediumRec<R>& M = S.media[entering ? above : below];
+                    const MediumRec<R> M = S.media[entering ? above : below];  // by value: the three coefficients in one round trip
                     // vacuum_medium (medium.hpp:34-37) and a uniform_medium without density: exp(-0 * d) = 1 exactly, so
                     // the three exponentials and the distance are only computed inside a medium that absorbs
-                    if(M.sigma[0] != R(0) || M.sigma[1] != R(0) || M.sigma[2] != R(0))
+                    if(static_cast<int>(M.sigma[0] != R(0)) | static_cast<int>(M.sigma[1] != R(0)) | static_cast<int>(M.sigma[2] != R(0)))
                     {
                         R dist = length(sp.p - p1);
                         beta = beta * vec3<R>{r_exp(-M.sigma[0] * dist), r_exp(-M.sigma[1] * dist), r_exp(-M.sigma[2] * dist)};  // medium.hpp:47-50
@@ -1109,7 +1121,9 @@ namespace fcg
                         else
                         {
                             // standard_light::sample_p, const_diffuse_area_light.hpp:28-42
-                            const LightRec<R>& Lt = S.lights[li];
+                            // by value: every field in one round trip (through a reference each field was fetched where it
+                            // is first used, i.e. one dependent round trip per basic block: kind, counts, radiance, area)
+                            const LightRec<R> Lt = S.lights[li];
 #if FCG_SHADE_LIGHT_FIRST
                             const vec3<R> pL = lf_pL, nL = lf_nL;
 #else
