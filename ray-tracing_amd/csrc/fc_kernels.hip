@@ -667,6 +667,16 @@ namespace fcg
 #endif
     constexpr int SORT_ITEMS = FCG_SORT_ITEMS;
 
+    // A block takes `sub` consecutive tiles of BLOCK * SORT_ITEMS hits per iteration and asks for its list space ONCE per key
+    // for all of them: the kernel was bound by the returning atomics on the four or five list counters (one word serves
+    // about 80 of them per microsecond: with one tile per atomic, 32 000 block iterations x 4 keys per full-size launch were
+    // 0.43 ms however the rest was written; 8 / 16 / 32 hits per thread and atomic measured 7.6 / 4.3 / 3.0 ms per step). Two
+    // passes over the block's tiles: count per wave and key, one atomic per key, then the same ballots again to place the
+    // indices (the key bytes of the second pass come from the L2). `sub` follows the queue length, so that short queues
+    // still spread over the whole grid.
+#ifndef FCG_SORT_SUB_MAX
+#define FCG_SORT_SUB_MAX 16
+#endif
     template<typename R>
     __global__ __launch_bounds__(BLOCK) void k_sort(Wavefront<R> Q, Batch B)
     {
@@ -674,32 +684,36 @@ namespace fcg
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const uint64_t lt = (1ull << lane) - 1ull;
         const uint32_t n = Q.counters->ray[B.parity][0];
-        for(uint32_t base = blockIdx.x * (BLOCK * SORT_ITEMS); base < n; base += gridDim.x * (BLOCK * SORT_ITEMS))
+        constexpr uint32_t TILE = BLOCK * SORT_ITEMS;
+        uint32_t sub = n / (gridDim.x * TILE);
+        sub = sub < 1u ? 1u : (sub > static_cast<uint32_t>(FCG_SORT_SUB_MAX) ? static_cast<uint32_t>(FCG_SORT_SUB_MAX) : sub);
+        const uint64_t chunk = static_cast<uint64_t>(TILE) * sub;
+        for(uint64_t base64 = blockIdx.x * chunk; base64 < n; base64 += gridDim.x * chunk)
         {
-            // item j of this thread is hit  base + j * BLOCK + threadIdx.x  (coalesced byte loads)
-            uint32_t key[SORT_ITEMS];
-            uint32_t pos[SORT_ITEMS];  // rank of the item among the wave's items of the same key
-            uint32_t wave_cnt = 0;     // lane k (< Q_COUNT) accumulates the wave's count of key k
-#pragma unroll
-            for(int j = 0; j < SORT_ITEMS; ++j)
+            const uint32_t base = static_cast<uint32_t>(base64);
+            // pass 1: lane k (< Q_COUNT) accumulates the wave's count of key k over the block's tiles
+            uint32_t wave_cnt = 0;
+            for(uint32_t t = 0; t < sub; ++t)
             {
-                uint32_t i = base + j * BLOCK + threadIdx.x;
-                key[j] = i < n ? Q.hit_key[i] : 0xFFu;
-                pos[j] = 0;
-            }
-#pragma unroll
-            for(int k = 0; k < Q_COUNT; ++k)
-            {
-                if(Q.hit_idx[k] == nullptr) continue;  // a key this scene cannot produce (no such lobe, no environment) has no list
-                uint32_t run = 0;
+                const uint32_t tile = base + t * TILE;
+                if(tile >= n) break;
+                // item j of this thread is hit  tile + j * BLOCK + threadIdx.x  (coalesced byte loads)
+                uint32_t key[SORT_ITEMS];
 #pragma unroll
                 for(int j = 0; j < SORT_ITEMS; ++j)
                 {
-                    uint64_t m = __ballot(key[j] == static_cast<uint32_t>(k));
-                    if(key[j] == static_cast<uint32_t>(k)) pos[j] = run + __popcll(m & lt);
-                    run += __popcll(m);
+                    const uint32_t i = tile + j * BLOCK + threadIdx.x;
+                    key[j] = i < n ? Q.hit_key[i] : 0xFFu;
                 }
-                if(lane == k) wave_cnt = run;
+#pragma unroll
+                for(int k = 0; k < Q_COUNT; ++k)
+                {
+                    if(Q.hit_idx[k] == nullptr) continue;  // a key this scene cannot produce (no such lobe, no environment) has no list
+                    uint32_t run = 0;
+#pragma unroll
+                    for(int j = 0; j < SORT_ITEMS; ++j) run += __popcll(__ballot(key[j] == static_cast<uint32_t>(k)));
+                    if(lane == k) wave_cnt += run;
+                }
             }
             if(lane < Q_COUNT) cnt_lds[lane][wave] = wave_cnt;
             __syncthreads();
@@ -718,12 +732,43 @@ namespace fcg
                 }
             }
             __syncthreads();
-#pragma unroll
-            for(int j = 0; j < SORT_ITEMS; ++j)
+            // pass 2: lane k holds where the wave's next index of key k goes
+            uint32_t next = lane < Q_COUNT ? cnt_lds[lane][wave] : 0u;
+            for(uint32_t t = 0; t < sub; ++t)
             {
-                if(key[j] != 0xFFu) Q.hit_idx[key[j]][cnt_lds[key[j]][wave] + pos[j]] = base + j * BLOCK + threadIdx.x;
+                const uint32_t tile = base + t * TILE;
+                if(tile >= n) break;
+                uint32_t key[SORT_ITEMS];
+                uint32_t pos[SORT_ITEMS];  // list position of the item
+#pragma unroll
+                for(int j = 0; j < SORT_ITEMS; ++j)
+                {
+                    const uint32_t i = tile + j * BLOCK + threadIdx.x;
+                    key[j] = i < n ? Q.hit_key[i] : 0xFFu;
+                    pos[j] = 0;
+                }
+#pragma unroll
+                for(int k = 0; k < Q_COUNT; ++k)
+                {
+                    if(Q.hit_idx[k] == nullptr) continue;
+                    const uint32_t first = static_cast<uint32_t>(__shfl(static_cast<int>(next), k));
+                    uint32_t run = 0;
+#pragma unroll
+                    for(int j = 0; j < SORT_ITEMS; ++j)
+                    {
+                        const uint64_t m = __ballot(key[j] == static_cast<uint32_t>(k));
+                        if(key[j] == static_cast<uint32_t>(k)) pos[j] = first + run + __popcll(m & lt);
+                        run += __popcll(m);
+                    }
+                    if(lane == k) next += run;
+                }
+#pragma unroll
+                for(int j = 0; j < SORT_ITEMS; ++j)
+                {
+                    if(key[j] != 0xFFu) Q.hit_idx[key[j]][pos[j]] = tile + j * BLOCK + threadIdx.x;
+                }
             }
-            __syncthreads();
+            __syncthreads();  // cnt_lds is reused by the next iteration
         }
     }
 
