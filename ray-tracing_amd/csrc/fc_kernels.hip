@@ -660,8 +660,8 @@ namespace fcg
         wave_stat_add(Q.stats, ST_PRIMS, n_prims);
     }
 
-    // material sort: index lists per queue key from hit_key[]. Each thread owns SORT_ITEMS consecutive
-    // hits, so a block compacts BLOCK * SORT_ITEMS hits with ONE global atomic per key.
+    // material sort: index lists per queue key from hit_key[]. A tile is BLOCK * SORT_ITEMS hits (SORT_ITEMS per thread,
+    // BLOCK apart, so that the byte loads coalesce); a block compacts up to FCG_SORT_SUB_MAX tiles with ONE global atomic per key.
 #ifndef FCG_SORT_ITEMS
 #define FCG_SORT_ITEMS 16
 #endif
