@@ -14,9 +14,10 @@ t0 = time.time(); sc = S.BUILDERS[name](width=w, height=h, **kw); print(f"scene 
 ctx = Rn.GpuContext(0)
 ctx.set_options(bvh_builder=bvh)
 t0 = time.time(); ctx.upload_scene(sc); up = time.time() - t0
-ctx.render_pass(0, 1); ctx.sync()
+ctx.render_pass(0, spp); ctx.sync()  # warm-up at the size of the timed pass: the queues are allocated (and the film cleared below) before the clock starts
+ctx.clear_film()
 ctx.set_profiling(True); ctx.stage_times(); ctx.reset_counters(); ctx.sync()
-t0 = time.time(); ctx.render_pass(1, spp); ctx.sync(); dt = time.time() - t0
+t0 = time.time(); ctx.render_pass(spp, spp); ctx.sync(); dt = time.time() - t0
 c = ctx.counters(); st = ctx.stage_times()
 rays = c.closest_rays + c.shadow_rays
 print(f"{name} {kw} bvh={bvh} {w}x{h} {spp} spp, {sc.primitive_total()} primitives: upload {up:.2f} s (flatten + BVH {c.reserved[6] / 1e6:.2f} s, "
