@@ -668,12 +668,11 @@ namespace fcg
     constexpr int SORT_ITEMS = FCG_SORT_ITEMS;
 
     // A block takes `sub` consecutive tiles of BLOCK * SORT_ITEMS hits per iteration and asks for its list space ONCE per key
-    // for all of them: the kernel was bound by the returning atomics on the four or five list counters (one word serves
-    // about 80 of them per microsecond: with one tile per atomic, 32 000 block iterations x 4 keys per full-size launch were
-    // 0.43 ms however the rest was written; 8 / 16 / 32 hits per thread and atomic measured 7.6 / 4.3 / 3.0 ms per step). Two
-    // passes over the block's tiles: count per wave and key, one atomic per key, then the same ballots again to place the
-    // indices (the key bytes of the second pass come from the L2). `sub` follows the queue length, so that short queues
-    // still spread over the whole grid.
+    // for all of them. The kernel's time followed its number of block iterations (8 / 16 / 32 hits per thread and iteration:
+    // 7.6 / 4.3 / 3.0 ms per step): an iteration is a dependent sequence (key bytes from memory, ballots, barrier, one returning
+    // atomic per key, barrier, index stores) that the few resident blocks of a CU do not overlap well. Two passes over the
+    // block's tiles: count per wave and key, one atomic per key, then the same ballots again to place the indices (the key bytes
+    // of the second pass come from the L2). `sub` follows the queue length, so that short queues still spread over the grid.
 #ifndef FCG_SORT_SUB_MAX
 #define FCG_SORT_SUB_MAX 16
 #endif
